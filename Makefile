@@ -1,0 +1,46 @@
+# Builds everything in-tree (the .so files travel to the GPU box with the snapshot).
+#   make            -> product library + oracle + scene generator
+#   make lib        -> pathtracer_amd/libhpt.so           (hipcc, gfx950)  the product
+#   make oracle     -> oracle/libpt_oracle.so             (gcc)            test infrastructure
+#   make scenes     -> scenes/libhpt_scenes.so            (gcc)            test/bench infrastructure
+HIPCC ?= /opt/rocm/bin/hipcc
+CC    ?= gcc
+CXX   ?= g++
+
+# No FMA contraction, IEEE divide/sqrt: the numerics contract of DESIGN.md §Numerics.
+HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off \
+           -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Iinclude -Wall -Wno-unused-function
+HOSTFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Wall
+CFLAGS_ORACLE = -O2 -std=c11 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -Wall
+
+LIB_SRC = pathtracer_amd/csrc/hpt_backend.hip
+HOST_SRC = pathtracer_amd/csrc/host/bvh.cpp pathtracer_amd/csrc/host/obj_reader.cpp \
+           pathtracer_amd/csrc/host/image_writer.cpp pathtracer_amd/csrc/host/pathtracer.cpp \
+           pathtracer_amd/csrc/host/host_capi.cpp
+HOST_OBJ = $(HOST_SRC:.cpp=.o)
+
+all: lib oracle scenes
+
+lib: pathtracer_amd/libhpt.so
+
+pathtracer_amd/csrc/host/%.o: pathtracer_amd/csrc/host/%.cpp $(wildcard pathtracer_amd/csrc/host/*.hpp) $(wildcard include/hpt/*.h)
+	$(CXX) $(HOSTFLAGS) -c $< -o $@
+
+pathtracer_amd/csrc/hpt_backend.o: $(LIB_SRC) $(wildcard pathtracer_amd/csrc/*.h) $(wildcard include/hpt/*.h)
+	$(HIPCC) $(HIPFLAGS) -c $(LIB_SRC) -o $@
+
+pathtracer_amd/libhpt.so: pathtracer_amd/csrc/hpt_backend.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC pathtracer_amd/csrc/hpt_backend.o $(HOST_OBJ) -o $@
+
+oracle: oracle/libpt_oracle.so
+oracle/libpt_oracle.so: oracle/pt_oracle.c oracle/pt_oracle.h include/hpt/types.h
+	$(CC) $(CFLAGS_ORACLE) -shared oracle/pt_oracle.c -o $@ -lm
+
+scenes: scenes/libhpt_scenes.so
+scenes/libhpt_scenes.so: scenes/scenes.c
+	$(CC) -O2 -std=c11 -fPIC -ffp-contract=off -shared scenes/scenes.c -o $@ -lm
+
+clean:
+	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o
+
+.PHONY: all lib oracle scenes clean

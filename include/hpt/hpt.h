@@ -1,0 +1,121 @@
+/* hpt/hpt.h — C-ABI of the MI355X (gfx950) HIP render backend.
+ *
+ * This is the drop-in boundary: one entry point per public method of the
+ * reference's device backend `class OpenCL_Manager`
+ * (reference pathtracer/opencl_manager.hpp:11-50), whose only caller is
+ * `class Pathtracer` (pathtracer/pathtracer.cpp:69-72, 142, 166, 180, 192, 301, 316).
+ * extern "C", plain pointers and sizes, opaque context.  Every function
+ * returns HPT_OK (0) or a negative hpt_status; hpt_last_error() gives the
+ * text.  Nothing in the library calls exit() (the reference does:
+ * opencl_manager.cpp:52-65, 113-130).
+ *
+ * Pointers named `d_*` are DEVICE pointers (HIP memory of the context's
+ * device); all others are host pointers.  One host thread per context.
+ */
+#ifndef HPT_HPT_H
+#define HPT_HPT_H
+
+#include "types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hpt_ctx hpt_ctx;
+
+typedef enum {
+    HPT_OK = 0,
+    HPT_ERR_INVALID = -1,   /* bad argument / call order */
+    HPT_ERR_DEVICE = -2,    /* HIP runtime error (text in hpt_last_error) */
+    HPT_ERR_NOMEM = -3,
+    HPT_ERR_BVH = -4        /* malformed BVH arrays (cycle, child out of range, depth > limit) */
+} hpt_status;
+
+/* Replaces OpenCL_Manager::initialize(width,height) + kernel_load()/new_kernel_load()
+ * (opencl_manager.hpp:13-19, opencl_manager.cpp:46-104, 107-187): kernels are
+ * compiled ahead of time for gfx950, so the load calls disappear.
+ * `device` is the HIP device ordinal. */
+int hpt_create(int width, int height, int device, hpt_ctx **out);
+int hpt_destroy(hpt_ctx *ctx);
+
+/* Text of the last error on this context (ctx == NULL: last hpt_create error). */
+const char *hpt_last_error(const hpt_ctx *ctx);
+
+/* Launch stream (a hipStream_t passed as void*; NULL = the null stream).
+ * No counterpart in the reference (it makes a new CommandQueue per call,
+ * opencl_manager.cpp:284, 394, 547, 590). */
+int hpt_set_stream(hpt_ctx *ctx, void *hip_stream);
+
+/* Image-tile shard of this context: rank r of `world` renders the 8x8-pixel
+ * tiles t with t % world == r.  Default (0,1) = whole image. */
+int hpt_set_shard(hpt_ctx *ctx, int rank, int world);
+
+/* Replaces OpenCL_Manager::triangles_to_texture (opencl_manager.hpp:21,
+ * opencl_manager.cpp:207-221).  Copies at call time. Triangles are in BVH leaf order. */
+int hpt_upload_triangles(hpt_ctx *ctx, const hpt_triangle *triangles, int n_triangles);
+
+/* Replaces OpenCL_Manager::bvh_to_texture (opencl_manager.hpp:22-24,
+ * opencl_manager.cpp:223-253).  Copies at call time; validates the tree and
+ * re-lays it out as 64-B two-child nodes. */
+int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *info, int n_nodes);
+
+/* Hoists the per-call re-uploads of primitives/materials/camera that every
+ * *_execute does (opencl_manager.cpp:287-291, 399-403, 595-599). */
+int hpt_set_scene(hpt_ctx *ctx, const hpt_primitive *primitives, int n_primitives,
+                  const hpt_material *materials, int n_materials);
+int hpt_set_camera(hpt_ctx *ctx, const hpt_camera *camera);
+
+/* The reference's compile-time literals (types.h hpt_config). */
+int hpt_set_config(hpt_ctx *ctx, const hpt_config *cfg);
+int hpt_get_config(const hpt_ctx *ctx, hpt_config *cfg);
+
+/* Replaces OpenCL_Manager::kernel_execute (opencl_manager.hpp:27-31,
+ * opencl_manager.cpp:569-648): ONE radiance sample per pixel of this shard
+ * for 0-based `iteration` (it selects the 6x6 jitter cell and keys the RNG).
+ * `image` receives width*height Pixels (pixels outside the shard are left 0). */
+int hpt_kernel_execute(hpt_ctx *ctx, hpt_pixel *image, int iteration);
+
+/* Replaces OpenCL_Manager::reconstruct_kernel_execute (opencl_manager.hpp:50,
+ * opencl_manager.cpp:532-566) with the arithmetic of the CPU running mean in
+ * Pathtracer::render() (pathtracer.cpp:200-217):
+ *   iterations == 1: image = sample;  else image = (1/it)*sample + ((it-1)/it)*image.
+ * Device pointers, n_pixels Pixels each. */
+int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_pixels, int iterations);
+
+/* kernel_execute + the running mean of Pathtracer::render() in one call,
+ * host image in/out (width*height*3 floats): what render() returns after
+ * iteration `iteration` given the image after `iteration-1`. */
+int hpt_render_sample(hpt_ctx *ctx, int iteration, float *image_rgb);
+
+/* Batched form: iterations spp_begin .. spp_end-1 accumulated into the
+ * device-resident running-mean image d_image (width*height*3 floats; read
+ * when spp_begin > 0).  Bit-identical to spp_end-spp_begin calls of
+ * hpt_render_sample.  Asynchronous on the context's stream. */
+int hpt_render(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image);
+
+/* Test hook for the bit-exact criterion: closest hit of the camera ray of
+ * `iteration` for every pixel of the full image (hit_id encoding in types.h,
+ * t = 1000 on a miss). Host arrays of width*height. */
+int hpt_primary_hits(hpt_ctx *ctx, int iteration, int32_t *hit_id, float *t);
+
+/* Multi-GPU exchange helpers (device pointers).  pack: this shard's tiles of
+ * d_image -> compact slab of hpt_slab_floats() floats; unpack: `world` slabs
+ * laid end to end (an all-gather result) -> full image. */
+int64_t hpt_slab_floats(const hpt_ctx *ctx);
+int hpt_pack_tiles(hpt_ctx *ctx, const float *d_image, float *d_slab);
+int hpt_unpack_tiles(hpt_ctx *ctx, const float *d_slabs, float *d_image);
+
+/* 8-bit output of png_writer.cpp:7-17 / main.cpp:147-149:
+ * (uint8)(255*clip(c,0,1)), truncation, no gamma. d_rgb8 = n_pixels*3 bytes. */
+int hpt_tonemap(hpt_ctx *ctx, const float *d_image, uint8_t *d_rgb8, int n_pixels);
+
+/* Blocks until the context's stream is idle. */
+int hpt_synchronize(hpt_ctx *ctx);
+
+/* Counters of the last hpt_render / hpt_kernel_execute (synchronizes). */
+int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPT_HPT_H */

@@ -1,0 +1,300 @@
+"""ctypes binding of pathtracer_amd/libhpt.so: the C-ABI of include/hpt/hpt.h
+plus the C entry points of the C++ host side (host/host_capi.cpp).
+
+This is the reference-side binding a maintainer would add, written for Python
+callers.  There is no fallback: without the HIP library the import of the
+render path fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import BBOX, CAMERA, INFO, MATERIAL, PRIMITIVE, TRIANGLE, Config, Stats
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhpt.so")
+_LIB = None
+
+# every symbol include/hpt/hpt.h declares
+C_ABI_SYMBOLS = [
+    "hpt_create", "hpt_destroy", "hpt_last_error", "hpt_set_stream", "hpt_set_shard", "hpt_upload_triangles",
+    "hpt_upload_bvh", "hpt_set_scene", "hpt_set_camera", "hpt_set_config", "hpt_get_config", "hpt_kernel_execute",
+    "hpt_reconstruct", "hpt_render_sample", "hpt_render", "hpt_primary_hits", "hpt_slab_floats", "hpt_pack_tiles",
+    "hpt_unpack_tiles", "hpt_tonemap", "hpt_synchronize", "hpt_get_stats",
+]
+
+
+class HptError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HptError("pathtracer_amd/libhpt.so is missing: build it with `make lib` "
+                           "(or __graft_entry__.build()); the render path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.hpt_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+        L.hpt_destroy.argtypes = [vp]
+        L.hpt_last_error.argtypes = [vp]; L.hpt_last_error.restype = C.c_char_p
+        L.hpt_set_stream.argtypes = [vp, vp]
+        L.hpt_set_shard.argtypes = [vp, i32, i32]
+        L.hpt_upload_triangles.argtypes = [vp, vp, i32]
+        L.hpt_upload_bvh.argtypes = [vp, vp, vp, i32]
+        L.hpt_set_scene.argtypes = [vp, vp, i32, vp, i32]
+        L.hpt_set_camera.argtypes = [vp, vp]
+        L.hpt_set_config.argtypes = [vp, C.POINTER(Config)]
+        L.hpt_get_config.argtypes = [vp, C.POINTER(Config)]
+        L.hpt_kernel_execute.argtypes = [vp, vp, i32]
+        L.hpt_reconstruct.argtypes = [vp, vp, vp, i32, i32]
+        L.hpt_render_sample.argtypes = [vp, i32, vp]
+        L.hpt_render.argtypes = [vp, i32, i32, vp]
+        L.hpt_primary_hits.argtypes = [vp, i32, vp, vp]
+        L.hpt_slab_floats.argtypes = [vp]; L.hpt_slab_floats.restype = C.c_int64
+        L.hpt_pack_tiles.argtypes = [vp, vp, vp]
+        L.hpt_unpack_tiles.argtypes = [vp, vp, vp]
+        L.hpt_tonemap.argtypes = [vp, vp, vp, i32]
+        L.hpt_synchronize.argtypes = [vp]
+        L.hpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        # host side
+        L.hpt_host_build_bvh.argtypes = [vp, i32, vp, vp, vp, vp, C.POINTER(i32)]
+        L.hpt_host_load_obj.argtypes = [C.c_char_p, vp, C.c_long]; L.hpt_host_load_obj.restype = C.c_long
+        L.hpt_host_save_png.argtypes = [vp, i32, i32, C.c_char_p]
+        L.hpt_host_save_ppm.argtypes = [vp, i32, i32, C.c_char_p]
+        L.hpt_host_save_png_rgb8.argtypes = [vp, i32, i32, C.c_char_p]
+        L.hpt_pathtracer_new.argtypes = [i32, i32, i32]; L.hpt_pathtracer_new.restype = vp
+        L.hpt_pathtracer_delete.argtypes = [vp]
+        L.hpt_pathtracer_error.argtypes = [vp]; L.hpt_pathtracer_error.restype = C.c_char_p
+        for n in ("set_scene_default", "set_camera_default", "get_iterations", "get_width", "get_height"):
+            getattr(L, "hpt_pathtracer_" + n).argtypes = [vp]
+        L.hpt_pathtracer_set_scene.argtypes = [vp, vp, i32, vp, i32]
+        L.hpt_pathtracer_set_camera.argtypes = [vp, vp]
+        L.hpt_pathtracer_set_config.argtypes = [vp, C.POINTER(Config)]
+        L.hpt_pathtracer_set_triangles.argtypes = [vp, vp, C.c_long]
+        L.hpt_pathtracer_render.argtypes = [vp]; L.hpt_pathtracer_render.restype = vp
+        L.hpt_pathtracer_render_n.argtypes = [vp, i32]; L.hpt_pathtracer_render_n.restype = vp
+        for n in ("iterative_render_first_bounce", "iterative_render", "reconstruct"):
+            getattr(L, "hpt_pathtracer_" + n).argtypes = [vp]; getattr(L, "hpt_pathtracer_" + n).restype = None
+        L.hpt_pathtracer_get_image.argtypes = [vp]; L.hpt_pathtracer_get_image.restype = vp
+        L.hpt_pathtracer_backend.argtypes = [vp]; L.hpt_pathtracer_backend.restype = vp
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------- host side
+def build_bvh(verts):
+    """verts (n,3,3) float32 -> dict(bbox, info, order, triangles, depth) by the C++ host builder
+    (host/bvh.cpp; order-exact with reference bvh.cpp)."""
+    verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 9)
+    n = len(verts)
+    bbox = np.zeros(max(2 * n, 1), BBOX); info = np.zeros(max(2 * n, 1), INFO)
+    order = np.zeros(n, np.int32); tris = np.zeros(n, TRIANGLE)
+    depth = C.c_int(0)
+    nn = lib().hpt_host_build_bvh(_p(verts), n, _p(bbox), _p(info), _p(order), _p(tris), C.byref(depth))
+    if nn < 0:
+        raise HptError("BVH build needs at least 12 triangles (reference bvh.cpp:242-261 reads vtriangles[0..11])")
+    return dict(bbox=bbox[:nn].copy(), info=info[:nn].copy(), order=order, triangles=tris, depth=depth.value)
+
+
+def load_obj(path):
+    n = lib().hpt_host_load_obj(os.fsencode(path), None, 0)
+    if n < 0:
+        raise HptError("load_obj failed: %s" % path)
+    out = np.zeros((n, 3), np.float32)
+    lib().hpt_host_load_obj(os.fsencode(path), _p(out), n)
+    return out
+
+
+def save_png(image_rgb, path):
+    img = np.ascontiguousarray(image_rgb, np.float32)
+    h, w = img.shape[0], img.shape[1]
+    if lib().hpt_host_save_png(_p(img), w, h, os.fsencode(path)) != 0:
+        raise HptError("save_png failed: %s" % path)
+
+
+# ---------------------------------------------------------------- device backend
+class Backend:
+    """One hpt_ctx.  Device buffers are passed as integer addresses (e.g. torch tensor .data_ptr())."""
+
+    def __init__(self, width, height, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.hpt_create(width, height, device, C.byref(h))
+        if rc != 0:
+            raise HptError("hpt_create: %s" % self.L.hpt_last_error(None).decode())
+        self.h = h
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hpt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HptError("hpt error %d: %s" % (rc, self.L.hpt_last_error(self.h).decode()))
+
+    def set_stream(self, stream_handle):
+        self._chk(self.L.hpt_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def set_shard(self, rank, world):
+        self._chk(self.L.hpt_set_shard(self.h, rank, world))
+
+    def upload_triangles(self, tris):
+        tris = np.ascontiguousarray(tris, TRIANGLE)
+        self._chk(self.L.hpt_upload_triangles(self.h, _p(tris), len(tris)))
+
+    def upload_bvh(self, bbox, info):
+        bbox = np.ascontiguousarray(bbox, BBOX); info = np.ascontiguousarray(info, INFO)
+        assert len(bbox) == len(info)
+        self._chk(self.L.hpt_upload_bvh(self.h, _p(bbox), _p(info), len(bbox)))
+
+    def set_scene(self, primitives, materials):
+        pr = np.ascontiguousarray(primitives, PRIMITIVE); mt = np.ascontiguousarray(materials, MATERIAL)
+        self._chk(self.L.hpt_set_scene(self.h, _p(pr), len(pr), _p(mt), len(mt)))
+
+    def set_camera(self, camera):
+        cam = np.ascontiguousarray(camera, CAMERA).reshape(1)
+        self._chk(self.L.hpt_set_camera(self.h, _p(cam)))
+
+    def set_config(self, cfg):
+        c = Config(int(cfg["max_depth"]), int(cfg["rr_start"]), float(cfg["diffuse_scale"]), int(cfg["seed"]))
+        self._chk(self.L.hpt_set_config(self.h, C.byref(c)))
+
+    def load(self, scn, bvh=None):
+        """Upload a pathtracer_amd.scenes.scene() dict, building the BVH on the host side."""
+        if bvh is None:
+            bvh = build_bvh(scn["verts"])
+        self.upload_bvh(bvh["bbox"], bvh["info"])
+        self.upload_triangles(bvh["triangles"])
+        self.set_scene(scn["primitives"], scn["materials"])
+        self.set_camera(scn["camera"])
+        self.set_config(scn["cfg"])
+        return bvh
+
+    def kernel_execute(self, iteration):
+        img = np.zeros((self.height * self.width, 3), np.float32)
+        self._chk(self.L.hpt_kernel_execute(self.h, _p(img), iteration))
+        return img
+
+    def render_sample(self, iteration, image):
+        assert image.dtype == np.float32 and image.size == self.width * self.height * 3 and image.flags.c_contiguous
+        self._chk(self.L.hpt_render_sample(self.h, iteration, _p(image)))
+        return image
+
+    def render(self, spp_begin, spp_end, d_image):
+        self._chk(self.L.hpt_render(self.h, spp_begin, spp_end, C.c_void_p(d_image)))
+
+    def reconstruct(self, d_image, d_sample, n_pixels, iterations):
+        self._chk(self.L.hpt_reconstruct(self.h, C.c_void_p(d_image), C.c_void_p(d_sample), n_pixels, iterations))
+
+    def primary_hits(self, iteration):
+        n = self.width * self.height
+        hit = np.empty(n, np.int32); t = np.empty(n, np.float32)
+        self._chk(self.L.hpt_primary_hits(self.h, iteration, _p(hit), _p(t)))
+        return hit, t
+
+    def slab_floats(self):
+        return int(self.L.hpt_slab_floats(self.h))
+
+    def pack_tiles(self, d_image, d_slab):
+        self._chk(self.L.hpt_pack_tiles(self.h, C.c_void_p(d_image), C.c_void_p(d_slab)))
+
+    def unpack_tiles(self, d_slabs, d_image):
+        self._chk(self.L.hpt_unpack_tiles(self.h, C.c_void_p(d_slabs), C.c_void_p(d_image)))
+
+    def tonemap(self, d_image, d_rgb8, n_pixels):
+        self._chk(self.L.hpt_tonemap(self.h, C.c_void_p(d_image), C.c_void_p(d_rgb8), n_pixels))
+
+    def synchronize(self):
+        self._chk(self.L.hpt_synchronize(self.h))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.hpt_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+
+class Pathtracer:
+    """The C++ facade (host/pathtracer.hpp) with the reference's method names
+    (reference pathtracer/pathtracer.hpp:55-76)."""
+
+    def __init__(self, w, h, device=0):
+        self.L = lib()
+        self.p = self.L.hpt_pathtracer_new(w, h, device)
+        if not self.p:
+            raise HptError("Pathtracer: %s" % self.L.hpt_last_error(None).decode())
+        self.w, self.h = w, h
+
+    def close(self):
+        if getattr(self, "p", None):
+            self.L.hpt_pathtracer_delete(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _img(self, ptr):
+        if not ptr:
+            raise HptError("Pathtracer: %s" % self.L.hpt_pathtracer_error(self.p).decode())
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(self.h, self.w, 3)).copy()
+
+    def set_scene(self, primitives=None, materials=None):
+        if primitives is None:
+            return self.L.hpt_pathtracer_set_scene_default(self.p)
+        pr = np.ascontiguousarray(primitives, PRIMITIVE); mt = np.ascontiguousarray(materials, MATERIAL)
+        return self.L.hpt_pathtracer_set_scene(self.p, _p(pr), len(pr), _p(mt), len(mt))
+
+    def set_camera(self, camera=None):
+        if camera is None:
+            return self.L.hpt_pathtracer_set_camera_default(self.p)
+        cam = np.ascontiguousarray(camera, CAMERA).reshape(1)
+        return self.L.hpt_pathtracer_set_camera(self.p, _p(cam))
+
+    def set_config(self, cfg):
+        c = Config(int(cfg["max_depth"]), int(cfg["rr_start"]), float(cfg["diffuse_scale"]), int(cfg["seed"]))
+        return self.L.hpt_pathtracer_set_config(self.p, C.byref(c))
+
+    def set_triangles(self, vertices):
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        return self.L.hpt_pathtracer_set_triangles(self.p, _p(v), len(v))
+
+    def render(self, n=None):
+        return self._img(self.L.hpt_pathtracer_render(self.p) if n is None else self.L.hpt_pathtracer_render_n(self.p, n))
+
+    def iterative_render_first_bounce(self):
+        self.L.hpt_pathtracer_iterative_render_first_bounce(self.p)
+
+    def iterative_render(self):
+        self.L.hpt_pathtracer_iterative_render(self.p)
+
+    def reconstruct(self):
+        self.L.hpt_pathtracer_reconstruct(self.p)
+
+    def get_image(self):
+        return self._img(self.L.hpt_pathtracer_get_image(self.p))
+
+    def get_iterations(self):
+        return self.L.hpt_pathtracer_get_iterations(self.p)
+
+    def get_width(self):
+        return self.L.hpt_pathtracer_get_width(self.p)
+
+    def get_height(self):
+        return self.L.hpt_pathtracer_get_height(self.p)

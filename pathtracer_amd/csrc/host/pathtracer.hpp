@@ -1,0 +1,61 @@
+// host/pathtracer.hpp — the renderer facade, same public methods as the
+// reference's class Pathtracer (reference pathtracer/pathtracer.hpp:55-76),
+// driving the HIP backend through the C-ABI of include/hpt/hpt.h where the
+// reference drives OpenCL_Manager (pathtracer.cpp:69-72, 142, 166, 180, 192, 301, 316).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/hpt/hpt.h"
+#include "bvh.hpp"
+
+namespace hpt {
+
+typedef hpt_pixel Pixel;
+
+class Pathtracer {
+public:
+    Pathtracer(int w, int h, int device = 0);
+    ~Pathtracer();
+    bool ok() const { return ctx != nullptr; }
+    const char *error() const;
+
+    // setters (reference: hard-coded scene and camera, pathtracer.cpp:224-263, 322-382)
+    int set_scene();
+    int set_scene(const std::vector<hpt_primitive> &prims, const std::vector<hpt_material> &mats);
+    int set_camera();
+    int set_camera(const hpt_camera &cam);
+    int set_triangles(std::vector<Vec3f> vertices);
+    int set_config(const hpt_config &cfg);
+
+    // One more sample per pixel folded into the running mean; returns the image
+    // (reference Pathtracer::render(), pathtracer.cpp:184-221).
+    Pixel *render();
+    // `n` samples in one device-resident batch; same image as n calls of render().
+    Pixel *render(int n);
+
+    // Progressive interface of the live GLUT loop (main.cpp:112, 130-131), with the
+    // semantics the reference intends: each iterative_render()
+    // produces one finished radiance sample per pixel, reconstruct() folds it in.
+    void iterative_render_first_bounce();
+    void iterative_render();
+    void reconstruct();
+
+    int get_width() const { return width; }
+    int get_height() const { return height; }
+    int get_iterations() const { return iterations; }
+    Pixel *get_image() { return image_data.data(); }
+    hpt_ctx *backend() { return ctx; }
+
+private:
+    hpt_ctx *ctx = nullptr;
+    int width, height, iterations = 0;
+    int pending_iteration = -1;              // sample produced by iterative_render(), not yet reconstructed
+    std::vector<Pixel> image_data, sample_data;
+    std::vector<hpt_triangle> triangles;
+    BoundingVolumeHierarchy bvh_constructor;
+    std::string create_error;
+    float *d_image = nullptr;                // device-resident running mean for render(n)
+};
+
+}  // namespace hpt

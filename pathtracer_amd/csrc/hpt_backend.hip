@@ -1,0 +1,484 @@
+// hpt_backend.hip — the C-ABI of include/hpt/hpt.h over the gfx950 kernels.
+//
+// Replaces the reference's device backend class OpenCL_Manager
+// (reference pathtracer/opencl_manager.{hpp,cpp}).  Differences in kind, not
+// in results: scene data is uploaded once and stays resident (the reference
+// re-creates every buffer and copies all per-pixel state both ways on every
+// call, opencl_manager.cpp:368-431, 515-523), errors come back as status codes
+// instead of exit(1), and the image/accumulation buffer lives in HBM.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hpt/hpt.h"
+#include "render_kernels.h"
+
+namespace {
+
+std::string g_create_error;
+
+constexpr int kMaxTreeDepth = 64;   // the reference's own bound: int todo[64], ray_kernel.cl:389
+constexpr int kBlock = 256;
+
+struct Buffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct hpt_ctx {
+    int device = 0;
+    int width = 0, height = 0;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 1;
+    hpt_config cfg{15, 3, 2.0f, 0x5EEDu};
+    hpt_camera cam{};
+    bool have_camera = false;
+
+    WideNode *d_nodes = nullptr;
+    int n_wide = 0;
+    int tree_depth = 0;
+    int max_leaf_end = 0;            // largest offset+count over the leaves, checked against n_tris at render
+    int root_ref = HPT_REF_DONE;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+
+    float4 *d_tris = nullptr;
+    int n_tris = 0;
+    hpt_primitive *d_prims = nullptr;
+    int n_prims = 0;
+    hpt_material *d_mats = nullptr;
+    int n_mats = 0;
+
+    unsigned int *d_work = nullptr;          // persistent-kernel work counter
+    unsigned long long *d_counters = nullptr;
+    float *d_sample = nullptr;               // width*height*3, kernel_execute / render_sample staging
+    float *d_accum = nullptr;                // width*height*3, render_sample staging
+    int32_t *d_hit_id = nullptr;
+    float *d_hit_t = nullptr;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int n_cu = 256;
+    int grid_waves = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(hpt_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(ctx, HPT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int bind(hpt_ctx *ctx) {
+    if (!ctx) return HPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return HPT_OK;
+}
+
+template <class T>
+int replace_buffer(hpt_ctx *ctx, T *&dptr, const void *host, size_t bytes) {
+    if (dptr) { HIP_TRY(ctx, hipFree(dptr)); dptr = nullptr; }
+    if (bytes == 0) return HPT_OK;
+    HIP_TRY(ctx, hipMalloc((void **)&dptr, bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // copy-at-call-time semantics of CL_MEM_COPY_HOST_PTR
+    return HPT_OK;
+}
+
+int tiles_x(const hpt_ctx *c) { return (c->width + 7) / 8; }
+int tiles_y(const hpt_ctx *c) { return (c->height + 7) / 8; }
+int n_tiles(const hpt_ctx *c) { return tiles_x(c) * tiles_y(c); }
+// tiles of the largest shard: every rank's slab has this many (all-gather wants equal sizes)
+int slab_tiles(const hpt_ctx *c) { return (n_tiles(c) + c->world - 1) / c->world; }
+
+int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, int spp_end, int raw) {
+    if (!ctx->have_camera) return fail(ctx, HPT_ERR_INVALID, "hpt_set_camera has not been called");
+    if (ctx->root_ref != HPT_REF_DONE && ctx->max_leaf_end > ctx->n_tris)
+        return fail(ctx, HPT_ERR_BVH, "BVH leaves reference triangle %d but only %d triangles are uploaded",
+                    ctx->max_leaf_end - 1, ctx->n_tris);
+    if ((long)ctx->width * ctx->height >= (1L << 24))
+        return fail(ctx, HPT_ERR_INVALID, "width*height must stay below 2^24 (pixel index is converted to float, "
+                                          "initial_ray_kernel.cl:863)");
+    memset(&p, 0, sizeof p);
+    p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.mats = ctx->d_mats;
+    p.image = d_image; p.hit_id = ctx->d_hit_id; p.hit_t = ctx->d_hit_t;
+    p.work_counter = ctx->d_work; p.counters = ctx->d_counters;
+    p.cam = ctx->cam;
+    for (int k = 0; k < 3; k++) { p.root_lo[k] = ctx->root_lo[k]; p.root_hi[k] = ctx->root_hi[k]; }
+    p.root_ref = ctx->root_ref;
+    p.width = ctx->width; p.height = ctx->height; p.n_prims = ctx->n_prims;
+    p.spp_begin = spp_begin; p.spp_end = spp_end;
+    p.max_depth = ctx->cfg.max_depth; p.rr_start = ctx->cfg.rr_start;
+    p.diffuse_scale = ctx->cfg.diffuse_scale; p.seed = ctx->cfg.seed;
+    p.rank = ctx->rank; p.world = ctx->world;
+    p.tiles_x = tiles_x(ctx); p.n_tiles = n_tiles(ctx);
+    int local_tiles = (p.n_tiles - ctx->rank + ctx->world - 1) / ctx->world;
+    if (local_tiles < 0) local_tiles = 0;
+    p.n_work = (uint32_t)local_tiles * 64u;
+    p.raw_sample = raw;
+    return HPT_OK;
+}
+
+size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
+    int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
+    return (size_t)depth * block * sizeof(uint2);
+}
+
+int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int raw) {
+    RenderParams p;
+    int rc = fill_params(ctx, p, d_image, spp_begin, spp_end, raw);
+    if (rc) return rc;
+    if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
+        return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    size_t lds = stack_lds_bytes(ctx, kBlock);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent grid: as many blocks as stay resident (LDS stack and VGPRs bound it), at most the work
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
+    if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: tree depth %d needs %zu B of LDS",
+                                ctx->tree_depth, lds);
+    long blocks = (long)per_cu * ctx->n_cu;
+    long need = ((long)p.n_work + kBlock - 1) / kBlock;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    ctx->grid_waves = (int)(blocks * (kBlock / 64));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return HPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hpt_last_error(const hpt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hpt_create(int width, int height, int device, hpt_ctx **out) {
+    if (!out) return fail(nullptr, HPT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (width <= 0 || height <= 0) return fail(nullptr, HPT_ERR_INVALID, "bad image size %dx%d", width, height);
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return fail(nullptr, HPT_ERR_DEVICE, "no HIP device (%s): the render path has no CPU fallback",
+                    e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n_dev) return fail(nullptr, HPT_ERR_INVALID, "device %d of %d", device, n_dev);
+    hpt_ctx *ctx = new hpt_ctx;
+    ctx->device = device; ctx->width = width; ctx->height = height;
+    auto bail = [&](const char *what, hipError_t err) {
+        fail(nullptr, HPT_ERR_DEVICE, "%s: %s", what, hipGetErrorString(err));
+        hpt_destroy(ctx);
+        return HPT_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->n_cu = prop.multiProcessorCount;
+    size_t img = (size_t)width * height * 3 * sizeof(float);
+    if ((e = hipMalloc((void **)&ctx->d_work, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_sample, img)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_accum, img)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_hit_id, (size_t)width * height * 4)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_hit_t, (size_t)width * height * 4)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    *out = ctx;
+    return HPT_OK;
+}
+
+int hpt_destroy(hpt_ctx *ctx) {
+    if (!ctx) return HPT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
+    (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return HPT_OK;
+}
+
+int hpt_set_stream(hpt_ctx *ctx, void *hip_stream) {
+    if (!ctx) return HPT_ERR_INVALID;
+    ctx->stream = (hipStream_t)hip_stream;
+    return HPT_OK;
+}
+
+int hpt_set_shard(hpt_ctx *ctx, int rank, int world) {
+    if (!ctx) return HPT_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, HPT_ERR_INVALID, "bad shard %d of %d", rank, world);
+    ctx->rank = rank; ctx->world = world;
+    return HPT_OK;
+}
+
+int hpt_upload_triangles(hpt_ctx *ctx, const hpt_triangle *triangles, int n_triangles) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_triangles < 0 || (n_triangles > 0 && !triangles)) return fail(ctx, HPT_ERR_INVALID, "bad triangle array");
+    if (n_triangles >= (1 << 25)) return fail(ctx, HPT_ERR_INVALID, "at most 2^25-1 triangles (leaf reference packing)");
+    rc = replace_buffer(ctx, ctx->d_tris, triangles, (size_t)n_triangles * sizeof(hpt_triangle));
+    if (rc) return rc;
+    ctx->n_tris = n_triangles;
+    return HPT_OK;
+}
+
+// Depth-first reference arrays -> 64-B two-child nodes.  Interior node k of the
+// reference becomes one WideNode holding the boxes of k+1 and secondChildOffset;
+// leaves live only as references in their parent.  Wide nodes are numbered in
+// the same pre-order, so a near-first descent walks forward in memory.
+int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *info, int n_nodes) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_nodes < 0 || (n_nodes > 0 && (!bbox || !info))) return fail(ctx, HPT_ERR_INVALID, "bad BVH arrays");
+    if (ctx->d_nodes) { HIP_TRY(ctx, hipFree(ctx->d_nodes)); ctx->d_nodes = nullptr; }
+    ctx->n_wide = 0; ctx->tree_depth = 0; ctx->max_leaf_end = 0; ctx->root_ref = HPT_REF_DONE;
+    if (n_nodes == 0) return HPT_OK;
+
+    auto leaf_ref = [&](int k, int &ref) -> int {
+        const hpt_bvh_info &n = info[k];
+        if (n.nPrimitives > HPT_LEAF_MAX_PRIMS)
+            return fail(ctx, HPT_ERR_BVH, "leaf %d has %d triangles (limit %d)", k, n.nPrimitives, HPT_LEAF_MAX_PRIMS);
+        if (n.offset < 0 || n.offset >= (1 << 25)) return fail(ctx, HPT_ERR_BVH, "leaf %d: bad triangle offset %d", k, n.offset);
+        if (n.offset + n.nPrimitives > ctx->max_leaf_end) ctx->max_leaf_end = n.offset + n.nPrimitives;
+        ref = HPT_LEAF_REF(n.offset, n.nPrimitives);
+        return HPT_OK;
+    };
+
+    // pass 1: walk the tree from node 0, number interior nodes in pre-order, validate
+    std::vector<int> wide_of(n_nodes, -1);
+    std::vector<unsigned char> seen(n_nodes, 0);
+    struct Item { int node, depth; };
+    std::vector<Item> todo;
+    todo.push_back({0, 0});
+    int n_wide = 0, depth_max = 0;
+    while (!todo.empty()) {
+        Item it = todo.back(); todo.pop_back();
+        int k = it.node;
+        if (k < 0 || k >= n_nodes) return fail(ctx, HPT_ERR_BVH, "child index %d out of range [0,%d)", k, n_nodes);
+        if (seen[k]) return fail(ctx, HPT_ERR_BVH, "node %d is reachable twice (not a tree)", k);
+        seen[k] = 1;
+        if (info[k].nPrimitives > 0) continue;
+        if (info[k].nPrimitives < 0) return fail(ctx, HPT_ERR_BVH, "node %d: negative nPrimitives", k);
+        if (info[k].axis < 0 || info[k].axis > 2) return fail(ctx, HPT_ERR_BVH, "node %d: axis %d", k, info[k].axis);
+        if (it.depth + 1 > kMaxTreeDepth)
+            return fail(ctx, HPT_ERR_BVH, "tree deeper than %d (the reference's todo[64] bound)", kMaxTreeDepth);
+        if (it.depth + 1 > depth_max) depth_max = it.depth + 1;
+        wide_of[k] = n_wide++;
+        todo.push_back({info[k].secondChildOffset, it.depth + 1});   // popped after the first child: pre-order
+        todo.push_back({k + 1, it.depth + 1});
+    }
+
+    // pass 2: fill
+    std::vector<WideNode> wide(n_wide);
+    for (int k = 0; k < n_nodes; k++) {
+        if (wide_of[k] < 0) continue;
+        WideNode &w = wide[wide_of[k]];
+        int c0 = k + 1, c1 = info[k].secondChildOffset;
+        w.lo0x = bbox[c0].minboundsx; w.lo0y = bbox[c0].minboundsy; w.lo0z = bbox[c0].minboundsz;
+        w.hi0x = bbox[c0].maxboundsx; w.hi0y = bbox[c0].maxboundsy; w.hi0z = bbox[c0].maxboundsz;
+        w.lo1x = bbox[c1].minboundsx; w.lo1y = bbox[c1].minboundsy; w.lo1z = bbox[c1].minboundsz;
+        w.hi1x = bbox[c1].maxboundsx; w.hi1y = bbox[c1].maxboundsy; w.hi1z = bbox[c1].maxboundsz;
+        w.axis = info[k].axis; w.pad = 0;
+        if (info[c0].nPrimitives > 0) { if ((rc = leaf_ref(c0, w.ref0))) return rc; } else w.ref0 = wide_of[c0];
+        if (info[c1].nPrimitives > 0) { if ((rc = leaf_ref(c1, w.ref1))) return rc; } else w.ref1 = wide_of[c1];
+    }
+    if (info[0].nPrimitives > 0) { if ((rc = leaf_ref(0, ctx->root_ref))) return rc; }
+    else ctx->root_ref = wide_of[0];
+    ctx->root_lo[0] = bbox[0].minboundsx; ctx->root_lo[1] = bbox[0].minboundsy; ctx->root_lo[2] = bbox[0].minboundsz;
+    ctx->root_hi[0] = bbox[0].maxboundsx; ctx->root_hi[1] = bbox[0].maxboundsy; ctx->root_hi[2] = bbox[0].maxboundsz;
+    rc = replace_buffer(ctx, ctx->d_nodes, wide.data(), wide.size() * sizeof(WideNode));
+    if (rc) { ctx->root_ref = HPT_REF_DONE; return rc; }
+    ctx->n_wide = n_wide;
+    ctx->tree_depth = depth_max;
+    return HPT_OK;
+}
+
+int hpt_set_scene(hpt_ctx *ctx, const hpt_primitive *primitives, int n_primitives,
+                  const hpt_material *materials, int n_materials) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_primitives < 0 || n_materials < 0 || (n_primitives > 0 && !primitives) || (n_materials > 0 && !materials))
+        return fail(ctx, HPT_ERR_INVALID, "bad scene arrays");
+    if ((rc = replace_buffer(ctx, ctx->d_prims, primitives, (size_t)n_primitives * sizeof(hpt_primitive)))) return rc;
+    if ((rc = replace_buffer(ctx, ctx->d_mats, materials, (size_t)n_materials * sizeof(hpt_material)))) return rc;
+    ctx->n_prims = n_primitives; ctx->n_mats = n_materials;
+    return HPT_OK;
+}
+
+int hpt_set_camera(hpt_ctx *ctx, const hpt_camera *camera) {
+    if (!ctx || !camera) return HPT_ERR_INVALID;
+    memcpy(&ctx->cam, camera, sizeof(hpt_camera));
+    ctx->have_camera = true;
+    return HPT_OK;
+}
+
+int hpt_set_config(hpt_ctx *ctx, const hpt_config *cfg) {
+    if (!ctx || !cfg) return HPT_ERR_INVALID;
+    if (cfg->max_depth < 0) return fail(ctx, HPT_ERR_INVALID, "max_depth %d", cfg->max_depth);
+    ctx->cfg = *cfg;
+    return HPT_OK;
+}
+
+int hpt_get_config(const hpt_ctx *ctx, hpt_config *cfg) {
+    if (!ctx || !cfg) return HPT_ERR_INVALID;
+    *cfg = ctx->cfg;
+    return HPT_OK;
+}
+
+int hpt_render(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image || spp_begin < 0 || spp_end < spp_begin) return fail(ctx, HPT_ERR_INVALID, "bad render range [%d,%d)", spp_begin, spp_end);
+    if (spp_end == spp_begin) return HPT_OK;
+    return launch_render(ctx, d_image, spp_begin, spp_end, 0);
+}
+
+int hpt_kernel_execute(hpt_ctx *ctx, hpt_pixel *image, int iteration) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!image || iteration < 0) return fail(ctx, HPT_ERR_INVALID, "bad kernel_execute arguments");
+    size_t img = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sample, 0, img, ctx->stream));
+    if ((rc = launch_render(ctx, ctx->d_sample, iteration, iteration + 1, 1))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(image, ctx->d_sample, img, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HPT_OK;
+}
+
+int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_pixels, int iterations) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image || !d_sample || n_pixels < 0) return fail(ctx, HPT_ERR_INVALID, "bad reconstruct arguments");
+    long n = 3L * n_pixels;
+    if (n == 0) return HPT_OK;
+    hipLaunchKernelGGL(reconstruct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, d_sample, n, iterations);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_render_sample(hpt_ctx *ctx, int iteration, float *image_rgb) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!image_rgb || iteration < 0) return fail(ctx, HPT_ERR_INVALID, "bad render_sample arguments");
+    size_t img = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_sample, 0, img, ctx->stream));
+    if ((rc = launch_render(ctx, ctx->d_sample, iteration, iteration + 1, 1))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, image_rgb, img, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = hpt_reconstruct(ctx, ctx->d_accum, ctx->d_sample, ctx->width * ctx->height, iteration + 1))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(image_rgb, ctx->d_accum, img, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HPT_OK;
+}
+
+int hpt_primary_hits(hpt_ctx *ctx, int iteration, int32_t *hit_id, float *t) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!hit_id || !t || iteration < 0) return fail(ctx, HPT_ERR_INVALID, "bad primary_hits arguments");
+    RenderParams p;
+    if ((rc = fill_params(ctx, p, nullptr, iteration, iteration + 1, 1))) return rc;
+    int npx = ctx->width * ctx->height;
+    size_t lds = stack_lds_bytes(ctx, kBlock);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)primary_hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(primary_hits_kernel, dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), lds, ctx->stream, p, iteration);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(hit_id, ctx->d_hit_id, (size_t)npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(t, ctx->d_hit_t, (size_t)npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HPT_OK;
+}
+
+int64_t hpt_slab_floats(const hpt_ctx *ctx) {
+    if (!ctx) return HPT_ERR_INVALID;
+    return (int64_t)slab_tiles(ctx) * 64 * 3;
+}
+
+int hpt_pack_tiles(hpt_ctx *ctx, const float *d_image, float *d_slab) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image || !d_slab) return fail(ctx, HPT_ERR_INVALID, "bad pack arguments");
+    RenderParams p;
+    memset(&p, 0, sizeof p);
+    p.width = ctx->width; p.height = ctx->height; p.rank = ctx->rank; p.world = ctx->world;
+    p.tiles_x = tiles_x(ctx); p.n_tiles = n_tiles(ctx);
+    unsigned n = (unsigned)slab_tiles(ctx) * 64u;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, p, d_image, d_slab, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_unpack_tiles(hpt_ctx *ctx, const float *d_slabs, float *d_image) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_slabs || !d_image) return fail(ctx, HPT_ERR_INVALID, "bad unpack arguments");
+    RenderParams p;
+    memset(&p, 0, sizeof p);
+    p.width = ctx->width; p.height = ctx->height; p.rank = 0; p.world = ctx->world;
+    p.tiles_x = tiles_x(ctx); p.n_tiles = n_tiles(ctx);
+    unsigned n = (unsigned)slab_tiles(ctx) * 64u;
+    unsigned total = n * (unsigned)ctx->world;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, p, d_slabs, d_image, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_tonemap(hpt_ctx *ctx, const float *d_image, uint8_t *d_rgb8, int n_pixels) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image || !d_rgb8 || n_pixels < 0) return fail(ctx, HPT_ERR_INVALID, "bad tonemap arguments");
+    long n = 3L * n_pixels;
+    if (n == 0) return HPT_OK;
+    hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, d_rgb8, n);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_synchronize(hpt_ctx *ctx) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HPT_OK;
+}
+
+int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!stats) return HPT_ERR_INVALID;
+    memset(stats, 0, sizeof *stats);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long c[3];
+    HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    stats->rays_primary = c[0]; stats->rays_bounce = c[1]; stats->paths = c[2];
+    if (ctx->timed) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        stats->last_kernel_ms = ms;
+    }
+    stats->wide_nodes = ctx->n_wide; stats->tree_depth = ctx->tree_depth; stats->grid_waves = ctx->grid_waves;
+    return HPT_OK;
+}
+
+}  // extern "C"

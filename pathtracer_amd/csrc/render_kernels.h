@@ -1,0 +1,427 @@
+// render_kernels.h — gfx950 device code of the render path.
+//
+// Replaces the reference's four OpenCL kernels:
+//   pathtracer_kernel  (pathtracer_kernel.cl:855-950)  -> render_kernel (whole path, fused running mean)
+//   initial_ray_kernel (initial_ray_kernel.cl:802-902) -> camera_ray() + closest_hit(), primary_hits_kernel
+//   ray_kernel         (ray_kernel.cl:817-929)         -> the bounce body in trace_path()
+//   reconstruct_kernel (reconstruct_kernel.cl:10-37)   -> reconstruct_kernel (arithmetic of pathtracer.cpp:200-217)
+// It is not a translation: the BVH is re-laid out as 64-B two-child nodes read
+// with four dwordx4 loads, each node visit tests both children, the per-lane
+// traversal stack lives in LDS, and pixels are handed to lanes by a persistent
+// work counter.  Results are bit-identical to the oracle's reference-order
+// traversal (argument in DESIGN.md §Traversal equivalence).
+#pragma once
+#include "device_math.h"
+#include "../../include/hpt/types.h"
+
+// 64-byte node: the boxes of both children of one interior node of the
+// reference tree (child0 = node k+1, child1 = secondChildOffset, bvh.cpp:382-386).
+// ref >= 0: index of the child's own WideNode; ref < 0: leaf, ~ref = (first triangle << 6) | (count-1).
+struct __attribute__((aligned(64))) WideNode {
+    float lo0x, lo0y, lo0z, hi0x;
+    float hi0y, hi0z, lo1x, lo1y;
+    float lo1z, hi1x, hi1y, hi1z;
+    int32_t ref0, ref1, axis, pad;
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be one 64-B line");
+
+#define HPT_REF_DONE 0x7fffffff
+#define HPT_LEAF_MAX_PRIMS 64
+#define HPT_LEAF_REF(offset, n) (~(((offset) << 6) | ((n) - 1)))
+
+struct RenderParams {
+    const WideNode *nodes;
+    const float4 *tris;              // hpt_triangle[] viewed as 3 x float4
+    const hpt_primitive *prims;
+    const hpt_material *mats;
+    float *image;                    // width*height*3
+    int32_t *hit_id;                 // primary_hits only
+    float *hit_t;
+    unsigned int *work_counter;
+    unsigned long long *counters;    // [0] primary rays [1] bounce rays [2] paths
+    hpt_camera cam;
+    float root_lo[3], root_hi[3];
+    int32_t root_ref;                // HPT_REF_DONE when there is no tree
+    int32_t width, height;
+    int32_t n_prims;
+    int32_t spp_begin, spp_end;
+    int32_t max_depth, rr_start;
+    float diffuse_scale;
+    uint32_t seed;
+    int32_t rank, world;
+    int32_t tiles_x, n_tiles;
+    uint32_t n_work;                 // local work items = local tiles * 64
+    int32_t raw_sample;              // 1: store the sample itself (kernel_execute), 0: running mean
+};
+
+struct Ray { f3 o, d; };
+
+// ---- camera ray: initial_ray_kernel.cl:859-883 (== pathtracer_kernel.cl:912-937) ----
+__device__ __forceinline__ Ray camera_ray(const RenderParams &p, int gid, int iteration, uint32_t key, uint32_t &ctr) {
+    const int n = 6;
+    float x = (float)(gid % p.width);            // fmod((float)gid,(float)width): exact for gid < 2^24
+    float y = (float)gid / (float)p.width;       // not floored
+    x = (x / (float)p.width) - 0.5f;
+    y = (y / (float)p.height) - 0.5f;
+    float left_limit = x - 1.0f / (float)(p.width + p.width);
+    float top_limit = y - 1.0f / (float)(p.height + p.height);
+    int cell = iteration % (n * n);
+    float inv_n_w = 1.0f / (float)(n * p.width);
+    float inv_n_h = 1.0f / (float)(n * p.height);
+    float r0 = draw(key, ctr);
+    float r1 = draw(key, ctr);
+    x = left_limit + ((float)(cell % n) + r0) * inv_n_w;
+    y = top_limit + ((float)(cell / n) + r1) * inv_n_h;
+    Ray r;
+    r.o = mk3(p.cam.eye.x, p.cam.eye.y, p.cam.eye.z);
+    f3 u = mk3(p.cam.u.x, p.cam.u.y, p.cam.u.z), v = mk3(p.cam.v.x, p.cam.v.y, p.cam.v.z);
+    f3 nn = mk3(p.cam.n.x, p.cam.n.y, p.cam.n.z);
+    r.d = normalize3((u * x + v * y) + (-nn));
+    return r;
+}
+
+// ---- slab test of ray_kernel.cl:321-377 split into its t-independent part
+// (returned) and tmin (compared with the current t by the caller) ----
+__device__ __forceinline__ bool slab(f3 lo, f3 hi, f3 o, f3 inv, bool nx, bool ny, bool nz, float &tmin_out) {
+    float tmin = ((nx ? hi.x : lo.x) - o.x) * inv.x;
+    float tmax = ((nx ? lo.x : hi.x) - o.x) * inv.x;
+    float tymin = ((ny ? hi.y : lo.y) - o.y) * inv.y;
+    float tymax = ((ny ? lo.y : hi.y) - o.y) * inv.y;
+    bool rej = (tmin > tymax) || (tymin > tmax);
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = ((nz ? hi.z : lo.z) - o.z) * inv.z;
+    float tzmax = ((nz ? lo.z : hi.z) - o.z) * inv.z;
+    rej = rej || (tmin > tzmax) || (tzmin > tmax);
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    tmin_out = tmin;
+    return !rej && (tmax > HPT_EPSILON);
+}
+
+// ---- Moller-Trumbore, ray_kernel.cl:467-520 ----
+__device__ __forceinline__ bool intersect_tri(const float4 *__restrict__ tris, int idx, f3 o, f3 d, float &t) {
+    const float4 *q = tris + 3 * (size_t)idx;
+    float4 v1 = q[0], e1 = q[1], e2 = q[2];
+    f3 edge1 = mk3(e1), edge2 = mk3(e2);
+    f3 pvec = cross3(d, edge2);
+    float det = dot3(edge1, pvec);
+    if (fabsf(det) < HPT_EPSILON) return false;
+    float invDet = 1.0f / det;
+    f3 tvec = o - mk3(v1);
+    float u = dot3(tvec, pvec) * invDet;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 qvec = cross3(tvec, edge1);
+    float v = dot3(d, qvec) * invDet;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float tt = dot3(edge2, qvec) * invDet;
+    if (tt < t && tt > 0.0f) { t = tt; return true; }
+    return false;
+}
+
+// ---- sphere / plane, ray_kernel.cl:524-602 ----
+__device__ __forceinline__ bool intersect_prim(const hpt_primitive *__restrict__ pr, f3 o, f3 d, float &t) {
+    float type = pr->type.x;
+    if (type == 0.0f) {
+        f3 oc = o - mk3(pr->center.x, pr->center.y, pr->center.z);
+        float radius = pr->radius;
+        float a = dot3(d, d);
+        float b = 2.0f * dot3(d, oc);
+        float c = dot3(oc, oc) - (radius * radius);
+        float disc = (b * b) - ((4.0f * a) * c);
+        float tt;
+        if (disc < 0.0f) return false;
+        else if (disc < HPT_EPSILON) tt = -b / (2.0f * a);
+        else {
+            disc = sqrtf(disc);
+            float t0 = (-b - disc) / (2.0f * a);
+            if (t0 > HPT_EPSILON) tt = t0;
+            else tt = (-b + disc) / (2.0f * a);
+        }
+        if (tt < t && tt > 0.0f) { t = tt; return true; }
+    } else if (type == 1.0f) {
+        f3 pn = mk3(pr->plane_normal.x, pr->plane_normal.y, pr->plane_normal.z);
+        float denom = dot3(pn, d);
+        if (fabsf(denom) > HPT_EPSILON) {
+            f3 between = mk3(pr->center.x, pr->center.y, pr->center.z) - o;
+            float tt = dot3(between, pn) / denom;
+            if (tt < t && tt >= 0.0f) { t = tt; return true; }
+        }
+    }
+    return false;
+}
+
+// ---- BVH traversal: same visits, same order, same t at every test as
+// intersect_tri_bvh (ray_kernel.cl:382-464), on the two-child node layout.
+// stack: LDS, entry e of this lane at stack[e * stride + lane]; .x = ref, .y = bits of the child's tmin.
+__device__ __forceinline__ int traverse(const RenderParams &p, f3 o, f3 d, float &t,
+                                        uint2 *__restrict__ stack, int stride) {
+    int hit = -1;
+    int cur = p.root_ref;
+    if (cur == HPT_REF_DONE) return hit;
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    {   // root: the node's own box, as the reference tests it
+        float tm;
+        bool ok = slab(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
+                       o, inv, nx, ny, nz, tm);
+        if (!(ok && tm < t)) return hit;
+    }
+    int sp = 0;
+    while (true) {
+        bool pop = false;
+        if (cur >= 0) {
+            const float4 *q = reinterpret_cast<const float4 *>(p.nodes + cur);
+            float4 a = q[0], b = q[1], c = q[2];
+            int4 m = *reinterpret_cast<const int4 *>(q + 3);
+            float t0, t1;
+            bool ok0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), o, inv, nx, ny, nz, t0);
+            bool ok1 = slab(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), o, inv, nx, ny, nz, t1);
+            bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
+            // near child first: dirIsNeg[axis] -> second child first (ray_kernel.cl:440-451)
+            bool second_first = (m.z == 0) ? nx : ((m.z == 1) ? ny : nz);
+            int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
+            bool hN = second_first ? h1 : h0, hF = second_first ? h0 : h1;
+            float tF = second_first ? t0 : t1;
+            if (hN) {
+                cur = refN;
+                if (hF) { stack[sp * stride] = make_uint2((unsigned)refF, __float_as_uint(tF)); sp++; }
+            } else if (hF) cur = refF;
+            else pop = true;
+        } else {
+            int packed = ~cur;
+            int first = packed >> 6, n = (packed & 63) + 1;
+            for (int i = 0; i < n; i++)
+                if (intersect_tri(p.tris, first + i, o, d, t)) hit = first + i;
+            pop = true;
+        }
+        if (pop) {
+            // the far child's box test, deferred by the reference to the pop, depends on t only through tmin < t
+            cur = HPT_REF_DONE;
+            while (sp > 0) {
+                sp--;
+                uint2 e = stack[sp * stride];
+                if (__uint_as_float(e.y) < t) { cur = (int)e.x; break; }
+            }
+            if (cur == HPT_REF_DONE) break;
+        }
+    }
+    return hit;
+}
+
+// closest hit: primitives loop, then the BVH (ray_kernel.cl:726-745)
+__device__ __forceinline__ int closest_hit(const RenderParams &p, f3 o, f3 d, float &t, uint2 *stack, int stride) {
+    int id = HPT_HIT_MISS;
+    t = 1000.0f;
+    for (int i = 0; i < p.n_prims; i++)
+        if (intersect_prim(p.prims + i, o, d, t)) id = HPT_HIT_PRIMITIVE(i);
+    int tri = traverse(p, o, d, t, stack, stride);
+    if (tri >= 0) id = tri;
+    return id;
+}
+
+// ---- shading helpers: ray_kernel.cl:244-256, 269-302, 615-706 ----
+struct Mat { float4 refractive, specular, diffuse, emissive; };
+
+__device__ __forceinline__ f3 sample_hemisphere(f3 normal, uint32_t key, uint32_t &ctr) {
+    float z = draw(key, ctr);
+    float r2 = draw(key, ctr);
+    float r = sqrtf(z);
+    float phi = 6.283185307179586f * r2;
+    float sn, cs;
+    sincos_2pi(phi, sn, cs);
+    float x = cs * r;
+    float y = sn * r;
+    z = sqrtf(1.0f - z);
+    f3 axis;
+    if (fabsf(normal.x) < HPT_ONE_THIRD_RT) axis = mk3(1, 0, 0);
+    else if (fabsf(normal.y) < HPT_ONE_THIRD_RT) axis = mk3(0, 1, 0);
+    else axis = mk3(0, 0, 1);
+    f3 u = normalize3(cross3(axis, normal));
+    f3 v = cross3(normal, u);
+    return (u * x + v * y) + normal * z;
+}
+__device__ __forceinline__ f3 reflect_dir(f3 n, f3 d) { return normalize3(d - n * (2.0f * dot3(n, d))); }
+__device__ __forceinline__ bool refract_dir(f3 D, f3 N, float index, f3 &out) {
+    float dn = dot3(D, N);
+    float a = 1.0f - (pow2f(index) * (1.0f - pow2f(dn)));
+    if (a < 0.0f) return false;
+    out = normalize3((D - N * dn) * index - N * sqrtf(a));
+    return true;
+}
+__device__ __forceinline__ float schlick_fresnel(f3 n, f3 d, float n2) {
+    float F0 = pow2f((1.0f - n2) / (1.0f + n2));
+    if (dot3(d, n) < 0.0f) return F0 + (1.0f - F0) * pow5f(1.0f - dot3(n, -d));
+    return F0 + (1.0f - F0) * pow5f(1.0f - dot3(n, d));
+}
+__device__ __forceinline__ f3 refractive_dir(f3 N, f3 d, float n) {
+    f3 tdir;
+    bool ok;
+    if (dot3(d, N) < 0.0f) ok = refract_dir(d, N, 1.0f / n, tdir);
+    else ok = refract_dir(d, -N, n, tdir);
+    if (ok) return tdir;
+    float ndoti = dot3(N, -d);
+    return N * (ndoti + ndoti) + d;
+}
+
+// ---- one radiance sample: the loop form pathtracer_kernel.cl:748-852 ----
+__device__ __forceinline__ f3 trace_path(const RenderParams &p, int gid, int iteration, uint2 *stack, int stride,
+                                         unsigned &n_primary, unsigned &n_bounce) {
+    uint32_t key = path_key(p.seed, (uint32_t)gid, (uint32_t)iteration), ctr = 0;
+    Ray r = camera_ray(p, gid, iteration, key, ctr);
+    f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+    for (int b = 0; b < p.max_depth; b++) {
+        float t;
+        int id = closest_hit(p, r.o, r.d, t, stack, stride);
+        if (b == 0) n_primary++; else n_bounce++;
+        if (id == HPT_HIT_MISS) {
+            color = color + weight * mk3(0.8f, 0.9f, 0.95f);       // BACKGROUND_COLOR, ray_kernel.cl:13
+            break;
+        }
+        f3 point = r.o + r.d * t;
+        f3 normal;
+        Mat m;
+        if (id >= 0) {
+            const float4 *q = p.tris + 3 * (size_t)id;
+            normal = normalize3(cross3(mk3(q[1]), mk3(q[2])));
+            if (dot3(normal, r.d) > 0.0f) normal = -normal;
+            const float4 *mm = reinterpret_cast<const float4 *>(p.mats);     // triangles use materials[0]
+            m.refractive = mm[0]; m.specular = mm[1]; m.diffuse = mm[2]; m.emissive = mm[3];
+        } else {
+            const hpt_primitive *pr = p.prims + (-id - 2);
+            const float4 *pp = reinterpret_cast<const float4 *>(pr);
+            m.refractive = pp[0]; m.specular = pp[1]; m.diffuse = pp[2]; m.emissive = pp[3];
+            if (pr->type.x == 0.0f) normal = normalize3(point - mk3(pp[4]));
+            else normal = normalize3(mk3(pp[6]));
+        }
+        if (m.emissive.y > 0.0f || m.emissive.z > 0.0f || m.emissive.w > 0.0f) {      // islight
+            color = color + weight * mk3(m.emissive);
+            break;
+        }
+        bool fresnel = draw(key, ctr) < schlick_fresnel(normal, r.d, m.refractive.x);
+        bool specular = (m.specular.x > HPT_EPSILON) || (m.specular.y > HPT_EPSILON) ||
+                        (m.specular.z > HPT_EPSILON) || (m.specular.w > HPT_EPSILON);
+        f3 nd;
+        if (fresnel && specular) nd = reflect_dir(normal, r.d);
+        else if (m.refractive.w == 1.0f) {
+            if (fresnel) nd = reflect_dir(normal, r.d);
+            else nd = refractive_dir(normal, r.d, m.refractive.x);
+        } else {
+            weight = weight * mk3(m.diffuse);
+            nd = sample_hemisphere(normal, key, ctr);
+            weight = weight * (dot3(normal, nd) * p.diffuse_scale);
+        }
+        f3 no = point + nd * HPT_EPSILON;
+        if (b > p.rr_start) {                                       // Russian roulette, pathtracer_kernel.cl:836-845
+            float mx = (weight.x > weight.y) ? weight.x : weight.y;
+            mx = (weight.z > mx) ? weight.z : mx;
+            float pterm = draw(key, ctr);
+            if (mx < pterm) break;
+            weight = mk3(weight.x / mx, weight.y / mx, weight.z / mx);
+        }
+        r.o = no; r.d = nd;
+    }
+    return color;
+}
+
+// work item -> pixel: 8x8 tiles, tile t belongs to rank t % world
+__device__ __forceinline__ int work_to_pixel(const RenderParams &p, unsigned work) {
+    int tile = (int)(work >> 6) * p.world + p.rank;
+    int k = (int)(work & 63u);
+    if (tile >= p.n_tiles) return -1;
+    int px = (tile % p.tiles_x) * 8 + (k & 7), py = (tile / p.tiles_x) * 8 + (k >> 3);
+    if (px >= p.width || py >= p.height) return -1;
+    return py * p.width + px;
+}
+
+extern __shared__ uint2 hpt_lds_stack[];
+
+// Persistent render kernel: each lane pulls pixels from a global counter and
+// carries the pixel's running mean (pathtracer.cpp:200-217) in registers over
+// its samples, so a pixel's samples are folded in iteration order whatever the
+// grid or the shard.
+__global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
+    uint2 *stack = hpt_lds_stack + threadIdx.x;
+    const int stride = blockDim.x;
+    unsigned n_primary = 0, n_bounce = 0, n_paths = 0;
+    while (true) {
+        unsigned work = atomicAdd(p.work_counter, 1u);
+        if (work >= p.n_work) break;
+        int gid = work_to_pixel(p, work);
+        if (gid < 0) continue;
+        float *px = p.image + 3 * (size_t)gid;
+        f3 mean = mk3(0, 0, 0);
+        if (p.spp_begin > 0 && !p.raw_sample) mean = mk3(px[0], px[1], px[2]);
+        for (int s = p.spp_begin; s < p.spp_end; s++) {
+            f3 c = trace_path(p, gid, s, stack, stride, n_primary, n_bounce);
+            n_paths++;
+            int it = s + 1;
+            if (it == 1 || p.raw_sample) mean = c;
+            else {
+                float i1 = 1.0f / (float)it;
+                float i2 = (float)(it - 1) / (float)it;
+                mean = mk3((i1 * c.x) + (i2 * mean.x), (i1 * c.y) + (i2 * mean.y), (i1 * c.z) + (i2 * mean.z));
+            }
+        }
+        px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
+    }
+    atomicAdd(p.counters + 0, (unsigned long long)n_primary);
+    atomicAdd(p.counters + 1, (unsigned long long)n_bounce);
+    atomicAdd(p.counters + 2, (unsigned long long)n_paths);
+}
+
+// closest hit of the camera ray, one lane per pixel (test hook)
+__global__ void __launch_bounds__(256) primary_hits_kernel(const RenderParams p, int iteration) {
+    uint2 *stack = hpt_lds_stack + threadIdx.x;
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= p.width * p.height) return;
+    uint32_t key = path_key(p.seed, (uint32_t)gid, (uint32_t)iteration), ctr = 0;
+    Ray r = camera_ray(p, gid, iteration, key, ctr);
+    float t;
+    int id = closest_hit(p, r.o, r.d, t, stack, blockDim.x);
+    p.hit_id[gid] = id;
+    p.hit_t[gid] = t;
+}
+
+// running mean of Pathtracer::render(), pathtracer.cpp:200-217 (the committed
+// reconstruct_kernel.cl swaps G/B and stops at gid 1000: not reproduced)
+__global__ void reconstruct_kernel(float *__restrict__ image, const float *__restrict__ sample, long n_floats, int iterations) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    if (iterations > 1) {
+        float i1 = 1.0f / (float)iterations;
+        float i2 = (float)(iterations - 1) / (float)iterations;
+        image[i] = (i1 * sample[i]) + (i2 * image[i]);
+    } else if (iterations == 1) image[i] = sample[i];
+}
+
+// png_writer.cpp:7-17: (uint8)(255 * max(0, min(c, 1))), truncation, NaN -> 0
+__global__ void tonemap_kernel(const float *__restrict__ image, uint8_t *__restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c = image[i];
+    float mn = (1.0f < c) ? 1.0f : c;
+    float cl = (0.0f < mn) ? mn : 0.0f;
+    out[i] = (uint8_t)(255.0f * cl);
+}
+
+// shard exchange: slab[(local_tile*64 + k)*3 + c] <-> image pixel
+__global__ void pack_tiles_kernel(const RenderParams p, const float *__restrict__ image, float *__restrict__ slab, unsigned n_slab_px) {
+    unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_slab_px) return;
+    int gid = work_to_pixel(p, w);
+    float r = 0, g = 0, b = 0;
+    if (gid >= 0) { r = image[3 * (size_t)gid]; g = image[3 * (size_t)gid + 1]; b = image[3 * (size_t)gid + 2]; }
+    slab[3 * (size_t)w] = r; slab[3 * (size_t)w + 1] = g; slab[3 * (size_t)w + 2] = b;
+}
+__global__ void unpack_tiles_kernel(RenderParams p, const float *__restrict__ slabs, float *__restrict__ image, unsigned n_slab_px) {
+    unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned total = n_slab_px * (unsigned)p.world;
+    if (w >= total) return;
+    p.rank = (int)(w / n_slab_px);
+    int gid = work_to_pixel(p, w % n_slab_px);
+    if (gid < 0) return;
+    image[3 * (size_t)gid] = slabs[3 * (size_t)w];
+    image[3 * (size_t)gid + 1] = slabs[3 * (size_t)w + 1];
+    image[3 * (size_t)gid + 2] = slabs[3 * (size_t)w + 2];
+}

@@ -1,0 +1,258 @@
+"""GPU parity tests: the HIP render path, called through the C-ABI (pathtracer_amd/libhpt.so),
+against the CPU oracle on the same inputs.
+
+Bar: BIT-EXACT.  Everything on the path is fp32 + - * / sqrt in a fixed order plus integer
+hashing, so hit ids, t, every radiance sample and every running mean
+must match the oracle bit for bit (NaNs compare equal to NaNs: conftest.bits).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits, get_scene
+from pathtracer_amd import api, dist, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def backend_for(s, bvh):
+    be = api.Backend(s["width"], s["height"])
+    be.load(s, bvh)
+    return be
+
+
+def dev_image(be, fill=None):
+    t = torch.zeros(be.width * be.height * 3, dtype=torch.float32, device="cuda")
+    if fill is not None:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(fill, np.float32).reshape(-1)))
+    return t
+
+
+def mismatch(a, b):
+    return int((bits(a) != bits(b)).sum())
+
+
+CASES = [("cornell", dict(width=256, height=256)),                  # C1 size, SURVEY.md §7.3
+         ("random", dict(n=2000, seed=1, width=128, height=128)),
+         ("random", dict(n=12, seed=3, width=64, height=64)),       # smallest tree the builder accepts
+         ("degenerate", dict(n_same=200, n_other=30, width=96, height=96)),
+         ("bunny", dict(width=160, height=160)),
+         ("sponza", dict(width=192, height=108))]
+
+
+@pytest.mark.parametrize("name,kw", CASES)
+def test_primary_hits_bit_exact(name, kw):
+    s, bvh, o = get_scene(name, **kw)
+    be = backend_for(s, bvh)
+    for it in (0, 17):
+        hit, t = be.primary_hits(it)
+        ohit, ot, _ = o.primary_hits(it)
+        assert np.array_equal(hit, ohit), "%d hit ids differ" % (hit != ohit).sum()
+        assert mismatch(t, ot) == 0
+    assert (ohit >= 0).any()
+
+
+@pytest.mark.parametrize("name,kw", CASES[:4] + [("bunny", dict(width=96, height=96)), ("sponza", dict(width=96, height=54))])
+def test_radiance_sample_bit_exact(name, kw):
+    """kernel_execute: one sample per pixel, every bounce, RNG draw order, Russian roulette."""
+    s, bvh, o = get_scene(name, **kw)
+    be = backend_for(s, bvh)
+    for it in (0, 5, 36):
+        img = be.kernel_execute(it)
+        oimg, cnt = o.kernel_execute(it)
+        assert mismatch(img, oimg) == 0
+        st = be.stats()
+        assert (st["rays_primary"], st["rays_bounce"], st["paths"]) == (cnt["rays_primary"], cnt["rays_bounce"], cnt["paths"])
+
+
+def test_glossy_and_refractive_materials_bit_exact():
+    """Triangle material with specular + IOR (the C5 material) and a transmissive triangle material."""
+    for spec, ior, trans in [((0.7, 0.7, 0.2), 1.9, False), ((0, 0, 0), 1.5, True)]:
+        s, bvh, o = get_scene("cornell", width=96, height=96)
+        s = dict(s)
+        s["materials"] = scenes.make_material((0.6, 0.4, 0.2), specular=spec, ior=ior, transmissive=trans)
+        s["cfg"] = dict(s["cfg"], max_depth=15)
+        from oracle import binding as orc
+        o2 = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], s["primitives"], s["materials"], s["camera"], 96, 96, s["cfg"])
+        be = backend_for(s, bvh)
+        for it in (0, 3):
+            assert mismatch(be.kernel_execute(it), o2.kernel_execute(it)[0]) == 0
+
+
+def test_running_mean_fused_and_stepwise():
+    """hpt_render over [0,n) == n x hpt_render_sample == oracle render (pathtracer.cpp:200-217)."""
+    s, bvh, o = get_scene("cornell", width=64, height=64)
+    be = backend_for(s, bvh)
+    oimg, _ = o.render(0, 6)
+    d = dev_image(be)
+    be.render(0, 6, d.data_ptr()); be.synchronize()
+    assert mismatch(d.cpu().numpy(), oimg) == 0
+    # split range: [0,2) then [2,6) continues the same running mean
+    d2 = dev_image(be)
+    be.render(0, 2, d2.data_ptr()); be.render(2, 6, d2.data_ptr()); be.synchronize()
+    assert mismatch(d2.cpu().numpy(), oimg) == 0
+    # host in/out form, one iteration per call
+    img = np.zeros((64 * 64, 3), np.float32)
+    for it in range(6):
+        be.render_sample(it, img)
+    assert mismatch(img, oimg) == 0
+    # kernel_execute + hpt_reconstruct on device
+    d3 = dev_image(be)
+    for it in range(6):
+        smp = dev_image(be, be.kernel_execute(it))
+        be.reconstruct(d3.data_ptr(), smp.data_ptr(), 64 * 64, it + 1)
+    be.synchronize()
+    assert mismatch(d3.cpu().numpy(), oimg) == 0
+
+
+def test_config_diffuse_scale_depth_and_rr():
+    s, bvh, o = get_scene("random", n=2000, seed=1, width=64, height=64)
+    from oracle import binding as orc
+    for cfg in [dict(max_depth=15, rr_start=3, diffuse_scale=1.0, seed=7),     # the iterative kernels' cos factor
+                dict(max_depth=2, rr_start=0, diffuse_scale=2.0, seed=0x5EED),
+                dict(max_depth=30, rr_start=1, diffuse_scale=2.0, seed=123456789)]:
+        s2 = dict(s, cfg=cfg)
+        o2 = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], s["primitives"], s["materials"], s["camera"], 64, 64, cfg)
+        be = backend_for(s2, bvh)
+        assert mismatch(be.kernel_execute(2), o2.kernel_execute(2)[0]) == 0
+
+
+@pytest.mark.parametrize("w,h,world", [(64, 64, 2), (100, 52, 3), (72, 40, 8)])
+def test_tile_shards_reassemble_bit_exact(w, h, world):
+    """Each shard renders only its 8x8 tiles; pack -> (all-gather) -> unpack gives the 1-GPU image."""
+    s, bvh, o = get_scene("cornell", width=w, height=h)
+    be = backend_for(s, bvh)
+    full = dev_image(be)
+    be.render(0, 3, full.data_ptr()); be.synchronize()
+    full = full.cpu().numpy().reshape(-1, 3)
+    assert mismatch(full, o.render(0, 3)[0]) == 0
+    n = None
+    slabs = []
+    for r in range(world):
+        be.set_shard(r, world)
+        n = be.slab_floats()
+        assert n == dist.slab_tiles(w, h, world) * 64 * 3
+        d = dev_image(be)
+        be.render(0, 3, d.data_ptr())
+        slab = torch.full((n,), -1.0, dtype=torch.float32, device="cuda")
+        be.pack_tiles(d.data_ptr(), slab.data_ptr()); be.synchronize()
+        part = d.cpu().numpy().reshape(-1, 3)
+        idx = dist.slab_pixel_index(w, h, r, world)
+        own = np.zeros(w * h, bool); own[idx[idx >= 0]] = True
+        assert mismatch(part[own], full[own]) == 0 and not part[~own].any()        # only its own tiles were touched
+        assert np.array_equal(slab.cpu().numpy().reshape(-1, 3), dist.pack_tiles_np(part, w, h, r, world))
+        slabs.append(slab)
+    out = dev_image(be)
+    be.unpack_tiles(torch.cat(slabs).data_ptr(), out.data_ptr()); be.synchronize()
+    assert mismatch(out.cpu().numpy(), full) == 0
+
+
+def test_tonemap_kernel():
+    from oracle import binding as orc
+    s, bvh, o = get_scene("cornell", width=64, height=64)
+    be = backend_for(s, bvh)
+    x = (np.random.default_rng(0).random(64 * 64 * 3, dtype=np.float32) * 1.5 - 0.25).astype(np.float32)
+    x[:3] = (np.nan, 1.0, 0.999)
+    d = dev_image(be, x)
+    out = torch.zeros(64 * 64 * 3, dtype=torch.uint8, device="cuda")
+    be.tonemap(d.data_ptr(), out.data_ptr(), 64 * 64); be.synchronize()
+    assert np.array_equal(out.cpu().numpy(), orc.tonemap(x))
+
+
+def test_single_leaf_tree_and_empty_tree():
+    """Edge cases of the seam: a BVH that is one leaf (hand-made arrays), and no BVH at all."""
+    from oracle import binding as orc
+    s, bvh, _ = get_scene("cornell", width=48, height=48)
+    tris = bvh["triangles"][:3].copy()
+    v = np.concatenate([tris["v1"][:, :3], tris["v1"][:, :3] + tris["e1"][:, :3], tris["v1"][:, :3] + tris["e2"][:, :3]])
+    bbox = np.zeros(1, api.BBOX); bbox["min"][0] = v.min(0); bbox["max"][0] = v.max(0)
+    info = np.zeros(1, api.INFO); info["nPrimitives"][0] = 3
+    o = orc.OracleScene(tris, bbox, info, s["primitives"], s["materials"], s["camera"], 48, 48, s["cfg"])
+    be = api.Backend(48, 48)
+    be.upload_bvh(bbox, info); be.upload_triangles(tris)
+    be.set_scene(s["primitives"], s["materials"]); be.set_camera(s["camera"]); be.set_config(s["cfg"])
+    hit, t = be.primary_hits(0)
+    oh, ot, _ = o.primary_hits(0)
+    assert np.array_equal(hit, oh) and mismatch(t, ot) == 0
+    assert mismatch(be.kernel_execute(1), o.kernel_execute(1)[0]) == 0
+    # no triangles: primitives only
+    o0 = orc.OracleScene(tris[:0], bbox[:0], info[:0], s["primitives"], s["materials"], s["camera"], 48, 48, s["cfg"])
+    be0 = api.Backend(48, 48)
+    be0.set_scene(s["primitives"], s["materials"]); be0.set_camera(s["camera"]); be0.set_config(s["cfg"])
+    assert mismatch(be0.kernel_execute(0), o0.kernel_execute(0)[0]) == 0
+
+
+def test_error_reporting():
+    s, bvh, _ = get_scene("cornell", width=32, height=32)
+    be = api.Backend(32, 32)
+    with pytest.raises(api.HptError, match="set_camera"):
+        be.kernel_execute(0)
+    bad = bvh["info"].copy()
+    bad["secondChildOffset"][0] = 10 ** 6
+    with pytest.raises(api.HptError, match="out of range"):
+        be.upload_bvh(bvh["bbox"], bad)
+    loop = bvh["info"].copy()
+    loop["secondChildOffset"][0] = 1                      # both children the same node
+    with pytest.raises(api.HptError, match="twice"):
+        be.upload_bvh(bvh["bbox"], loop)
+    be.upload_bvh(bvh["bbox"], bvh["info"])
+    be.upload_triangles(bvh["triangles"][:5])             # leaves point past the triangle array
+    be.set_scene(s["primitives"], s["materials"]); be.set_camera(s["camera"])
+    with pytest.raises(api.HptError, match="triangles are uploaded"):
+        be.kernel_execute(0)
+    with pytest.raises(api.HptError):
+        be.set_shard(3, 2)
+
+
+def test_pathtracer_facade_matches_oracle():
+    """The C++ facade with the reference's method names: set_triangles -> BVH build -> upload -> render()."""
+    s, bvh, o = get_scene("cornell", width=64, height=64)
+    pt = api.Pathtracer(64, 64)
+    assert pt.set_triangles(s["verts"].reshape(-1, 3)) == 1
+    assert pt.set_scene(s["primitives"], s["materials"]) == 1
+    assert pt.set_camera() == 1                          # the reference's fixed camera == scenes.default_camera()
+    assert pt.set_config(s["cfg"]) == 1
+    oimg = o.render(0, 3)[0]
+    for _ in range(3):
+        img = pt.render()
+    assert pt.get_iterations() == 3 and mismatch(img, oimg) == 0
+    img = pt.render(2)                                   # batched continuation
+    assert mismatch(img, o.render(3, 5, image=oimg.copy())[0]) == 0
+    pt2 = api.Pathtracer(64, 64)
+    pt2.set_triangles(s["verts"].reshape(-1, 3)); pt2.set_scene(s["primitives"], s["materials"]); pt2.set_camera(); pt2.set_config(s["cfg"])
+    pt2.iterative_render_first_bounce()
+    for _ in range(3):
+        pt2.iterative_render(); pt2.reconstruct()
+    assert mismatch(pt2.get_image(), oimg) == 0
+
+
+def test_full_size_properties_c3():
+    """BASELINE config C3 at full size (262 267 triangles, 1920x1080), checked through size-independent
+    properties plus oracle spot checks: (1) shards reassemble to the unsharded image, (2) a split spp
+    range continues the same running mean, (3) re-rendering is idempotent, (4) three pixel rows equal
+    the oracle bit for bit, (5) ray counters equal paths + bounces."""
+    s, bvh, o = get_scene("sponza")
+    be = backend_for(s, bvh)
+    w, h = s["width"], s["height"]
+    a = dev_image(be)
+    be.render(0, 2, a.data_ptr()); be.synchronize()
+    st = be.stats()
+    assert st["paths"] == 2 * w * h and st["rays_primary"] == st["paths"] and st["rays_bounce"] > st["paths"]
+    b = dev_image(be)
+    be.render(0, 1, b.data_ptr()); be.render(1, 2, b.data_ptr()); be.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    c = dev_image(be)
+    slabs = []
+    for r in range(4):
+        be.set_shard(r, 4)
+        d = dev_image(be)
+        be.render(0, 2, d.data_ptr())
+        slab = torch.empty(be.slab_floats(), dtype=torch.float32, device="cuda")
+        be.pack_tiles(d.data_ptr(), slab.data_ptr()); be.synchronize()
+        slabs.append(slab)
+    be.unpack_tiles(torch.cat(slabs).data_ptr(), c.data_ptr()); be.synchronize()
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    img = a.cpu().numpy().reshape(-1, 3)
+    for row in (3, 540, 1077):
+        oimg, _ = o.render(0, 2, px_begin=row * w, px_end=(row + 1) * w)
+        assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0

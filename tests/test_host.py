@@ -1,0 +1,110 @@
+"""CPU tests of the product's host side (C++: BVH builder, OBJ reader, image writer) against the
+oracle's restatements, and of the C-ABI surface (load + exported symbols, no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, get_scene
+from oracle import binding as orc
+from pathtracer_amd import api, scenes
+
+
+@pytest.mark.parametrize("name,kw", [("cornell", {}), ("random", dict(n=2000, seed=1)), ("random", dict(n=12, seed=3)),
+                                     ("random", dict(n=777, seed=9, extent=5.0, size=30.0)),
+                                     ("degenerate", dict(n_same=200, n_other=30)), ("bunny", {}), ("sponza", {})])
+def test_host_bvh_is_order_exact(name, kw):
+    """host/bvh.cpp must reproduce the bvh.cpp restatement byte for byte (node boxes, leaf sizes and
+    offsets, child links, axes, triangle order): hit order on ties depends on it."""
+    s = scenes.scene(name, **kw)
+    b = api.build_bvh(s["verts"])
+    ob, oi, oo = orc.build_bvh(s["verts"])
+    assert len(b["bbox"]) == len(ob)
+    assert b["bbox"].tobytes() == ob.tobytes()
+    assert b["info"].tobytes() == oi.tobytes()
+    assert np.array_equal(b["order"], oo)
+    assert b["triangles"].tobytes() == orc.make_triangles(s["verts"], oo).tobytes()
+    # depth reported by the builder = interior nodes on the longest root-to-leaf path
+    depth = np.zeros(len(oi), np.int32)
+    for k in range(len(oi)):
+        if oi["nPrimitives"][k] == 0:
+            depth[k + 1] = depth[oi["secondChildOffset"][k]] = depth[k] + 1
+    assert b["depth"] == depth.max()
+
+
+def test_host_bvh_rejects_small_input():
+    with pytest.raises(api.HptError):
+        api.build_bvh(np.zeros((11, 3, 3), np.float32))
+
+
+def test_obj_reader_matches_oracle_and_extends(tmp_path):
+    p = tmp_path / "a.obj"
+    p.write_text("# c\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1.5\nvn 0 0 1\nf 1 2 3\nf 1 3 4\n")
+    n, want = orc.load_obj(str(p))
+    got = api.load_obj(str(p))
+    assert np.array_equal(got, want)
+    q = tmp_path / "b.obj"                      # beyond the reference: v/vt/vn, negative indices, quads
+    q.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1/1/1 2/2/2 3/3/3 4/4/4\nf -4 -3 -2\n")
+    got = api.load_obj(str(q))
+    assert got.shape == (9, 3)
+    assert np.array_equal(got[:6], np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32))
+    with pytest.raises(api.HptError):
+        api.load_obj(str(tmp_path / "missing.obj"))
+    r = tmp_path / "c.obj"
+    r.write_text("v 0 0 0\nf 1 2 3\n")        # index out of range: the reference reads out of bounds, this one fails
+    with pytest.raises(api.HptError):
+        api.load_obj(str(r))
+
+
+def test_png_writer_round_trip(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = (rng.random((37, 53, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    img[0, 0] = (np.nan, 2.0, -1.0)
+    path = tmp_path / "o.png"
+    api.save_png(img, str(path))
+    back = np.asarray(Image.open(str(path)).convert("RGB"))
+    assert np.array_equal(back, orc.tonemap(img))           # (uint8)(255*clip(c,0,1)), png_writer.cpp:11-17
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "hpt", "hpt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(hpt_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(api.C_ABI_SYMBOLS)
+    L = C.CDLL(api.LIB_PATH)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.HptError, match="no CPU fallback|no HIP device"):
+        api.Backend(16, 16)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "pathtracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pt_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_tile_exchange_index_math():
+    from pathtracer_amd import dist
+    for (w, h, world) in [(64, 64, 1), (100, 52, 2), (1920, 1080, 8), (13, 9, 3)]:
+        seen = np.zeros(w * h, np.int32)
+        for r in range(world):
+            idx = dist.slab_pixel_index(w, h, r, world)
+            assert len(idx) == dist.slab_tiles(w, h, world) * 64
+            np.add.at(seen, idx[idx >= 0], 1)
+        assert (seen == 1).all()                # every pixel belongs to exactly one shard
+        img = np.random.default_rng(1).random((w * h, 3), dtype=np.float32)
+        slabs = np.stack([dist.pack_tiles_np(img, w, h, r, world) for r in range(world)])
+        assert np.array_equal(dist.unpack_tiles_np(slabs, w, h, world), img)
