@@ -29,6 +29,8 @@ def dev_image(be, fill=None):
 
 
 def mismatch(a, b):
+    a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+    assert a.shape == b.shape
     return int((bits(a) != bits(b)).sum())
 
 
