@@ -264,64 +264,58 @@ __device__ __forceinline__ f3 refractive_dir(f3 N, f3 d, float n) {
     return N * (ndoti + ndoti) + d;
 }
 
-// ---- one radiance sample: the loop form pathtracer_kernel.cl:748-852 ----
-__device__ __forceinline__ f3 trace_path(const RenderParams &p, int gid, int iteration, uint2 *stack, int stride,
-                                         unsigned &n_primary, unsigned &n_bounce) {
-    uint32_t key = path_key(p.seed, (uint32_t)gid, (uint32_t)iteration), ctr = 0;
-    Ray r = camera_ray(p, gid, iteration, key, ctr);
-    f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
-    for (int b = 0; b < p.max_depth; b++) {
-        float t;
-        int id = closest_hit(p, r.o, r.d, t, stack, stride);
-        if (b == 0) n_primary++; else n_bounce++;
-        if (id == HPT_HIT_MISS) {
-            color = color + weight * mk3(0.8f, 0.9f, 0.95f);       // BACKGROUND_COLOR, ray_kernel.cl:13
-            break;
-        }
-        f3 point = r.o + r.d * t;
-        f3 normal;
-        Mat m;
-        if (id >= 0) {
-            const float4 *q = p.tris + 3 * (size_t)id;
-            normal = normalize3(cross3(mk3(q[1]), mk3(q[2])));
-            if (dot3(normal, r.d) > 0.0f) normal = -normal;
-            const float4 *mm = reinterpret_cast<const float4 *>(p.mats);     // triangles use materials[0]
-            m.refractive = mm[0]; m.specular = mm[1]; m.diffuse = mm[2]; m.emissive = mm[3];
-        } else {
-            const hpt_primitive *pr = p.prims + (-id - 2);
-            const float4 *pp = reinterpret_cast<const float4 *>(pr);
-            m.refractive = pp[0]; m.specular = pp[1]; m.diffuse = pp[2]; m.emissive = pp[3];
-            if (pr->type.x == 0.0f) normal = normalize3(point - mk3(pp[4]));
-            else normal = normalize3(mk3(pp[6]));
-        }
-        if (m.emissive.y > 0.0f || m.emissive.z > 0.0f || m.emissive.w > 0.0f) {      // islight
-            color = color + weight * mk3(m.emissive);
-            break;
-        }
-        bool fresnel = draw(key, ctr) < schlick_fresnel(normal, r.d, m.refractive.x);
-        bool specular = (m.specular.x > HPT_EPSILON) || (m.specular.y > HPT_EPSILON) ||
-                        (m.specular.z > HPT_EPSILON) || (m.specular.w > HPT_EPSILON);
-        f3 nd;
-        if (fresnel && specular) nd = reflect_dir(normal, r.d);
-        else if (m.refractive.w == 1.0f) {
-            if (fresnel) nd = reflect_dir(normal, r.d);
-            else nd = refractive_dir(normal, r.d, m.refractive.x);
-        } else {
-            weight = weight * mk3(m.diffuse);
-            nd = sample_hemisphere(normal, key, ctr);
-            weight = weight * (dot3(normal, nd) * p.diffuse_scale);
-        }
-        f3 no = point + nd * HPT_EPSILON;
-        if (b > p.rr_start) {                                       // Russian roulette, pathtracer_kernel.cl:836-845
-            float mx = (weight.x > weight.y) ? weight.x : weight.y;
-            mx = (weight.z > mx) ? weight.z : mx;
-            float pterm = draw(key, ctr);
-            if (mx < pterm) break;
-            weight = mk3(weight.x / mx, weight.y / mx, weight.z / mx);
-        }
-        r.o = no; r.d = nd;
+// ---- one bounce of the loop body pathtracer_kernel.cl:759-849, after the closest hit (id, t) of
+// ray r is known.  Returns true when the path goes on with the new ray left in r (the caller then
+// advances b and stops at max_depth), false when it ended (light, miss, Russian roulette).
+__device__ __forceinline__ bool shade_bounce(const RenderParams &p, int id, float t, Ray &r, uint32_t key, uint32_t &ctr,
+                                             int b, f3 &color, f3 &weight) {
+    if (id == HPT_HIT_MISS) {
+        color = color + weight * mk3(0.8f, 0.9f, 0.95f);           // BACKGROUND_COLOR, ray_kernel.cl:13
+        return false;
     }
-    return color;
+    f3 point = r.o + r.d * t;
+    f3 normal;
+    Mat m;
+    if (id >= 0) {
+        const float4 *q = p.tris + 3 * (size_t)id;
+        normal = normalize3(cross3(mk3(q[1]), mk3(q[2])));
+        if (dot3(normal, r.d) > 0.0f) normal = -normal;
+        const float4 *mm = reinterpret_cast<const float4 *>(p.mats);         // triangles use materials[0]
+        m.refractive = mm[0]; m.specular = mm[1]; m.diffuse = mm[2]; m.emissive = mm[3];
+    } else {
+        const hpt_primitive *pr = p.prims + (-id - 2);
+        const float4 *pp = reinterpret_cast<const float4 *>(pr);
+        m.refractive = pp[0]; m.specular = pp[1]; m.diffuse = pp[2]; m.emissive = pp[3];
+        if (pr->type.x == 0.0f) normal = normalize3(point - mk3(pp[4]));
+        else normal = normalize3(mk3(pp[6]));
+    }
+    if (m.emissive.y > 0.0f || m.emissive.z > 0.0f || m.emissive.w > 0.0f) {          // islight
+        color = color + weight * mk3(m.emissive);
+        return false;
+    }
+    bool fresnel = draw(key, ctr) < schlick_fresnel(normal, r.d, m.refractive.x);
+    bool specular = (m.specular.x > HPT_EPSILON) || (m.specular.y > HPT_EPSILON) ||
+                    (m.specular.z > HPT_EPSILON) || (m.specular.w > HPT_EPSILON);
+    f3 nd;
+    if (fresnel && specular) nd = reflect_dir(normal, r.d);
+    else if (m.refractive.w == 1.0f) {
+        if (fresnel) nd = reflect_dir(normal, r.d);
+        else nd = refractive_dir(normal, r.d, m.refractive.x);
+    } else {
+        weight = weight * mk3(m.diffuse);
+        nd = sample_hemisphere(normal, key, ctr);
+        weight = weight * (dot3(normal, nd) * p.diffuse_scale);
+    }
+    f3 no = point + nd * HPT_EPSILON;
+    if (b > p.rr_start) {                                           // Russian roulette, pathtracer_kernel.cl:836-845
+        float mx = (weight.x > weight.y) ? weight.x : weight.y;
+        mx = (weight.z > mx) ? weight.z : mx;
+        float pterm = draw(key, ctr);
+        if (mx < pterm) return false;
+        weight = mk3(weight.x / mx, weight.y / mx, weight.z / mx);
+    }
+    r.o = no; r.d = nd;
+    return true;
 }
 
 // work item -> pixel: 8x8 tiles, tile t belongs to rank t % world
@@ -336,34 +330,153 @@ __device__ __forceinline__ int work_to_pixel(const RenderParams &p, unsigned wor
 
 extern __shared__ uint2 hpt_lds_stack[];
 
-// Persistent render kernel: each lane pulls pixels from a global counter and
-// carries the pixel's running mean (pathtracer.cpp:200-217) in registers over
-// its samples, so a pixel's samples are folded in iteration order whatever the
-// grid or the shard.
+// running mean of Pathtracer::render(), pathtracer.cpp:200-217; it = 1-based iteration
+__device__ __forceinline__ f3 fold_sample(f3 mean, f3 c, int it, bool raw) {
+    if (it == 1 || raw) return c;
+    float i1 = 1.0f / (float)it;
+    float i2 = (float)(it - 1) / (float)it;
+    return mk3((i1 * c.x) + (i2 * mean.x), (i1 * c.y) + (i2 * mean.y), (i1 * c.z) + (i2 * mean.z));
+}
+
+#define HPT_CUR_LEAF (-1)
+#ifndef HPT_SHADE_THRESHOLD
+#define HPT_SHADE_THRESHOLD 20
+#endif
+
+// Persistent wavefront render kernel.
+//
+// Every lane owns one pixel at a time and carries that pixel's running mean in registers over its
+// samples (so samples fold in iteration order whatever the grid or the shard).  A lane is always
+// in one of three states: NODE (an interior two-child node to test), TRI (a leaf with triangles
+// left, one per step) or SHADE (its ray's traversal is over: shade, Russian roulette, next ray /
+// next sample / next pixel from the global work counter).  Each trip of the loop the wave counts
+// its lanes per state with three 64-bit ballots and executes ONE step kind, chosen wave-uniformly
+// (scalar branch): a lane never waits for another lane's longer traversal, longer path or longer
+// leaf, which is what held the one-path-per-lane form at 12 % lane utilisation (profiles/r01_v1_naive).
+// SHADE is the expensive, rare step, so it waits until HPT_SHADE_THRESHOLD lanes want it or nothing
+// else is runnable.  Work order per lane is unchanged, so results stay bit-identical to the oracle.
 __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;
-    while (true) {
-        unsigned work = atomicAdd(p.work_counter, 1u);
-        if (work >= p.n_work) break;
-        int gid = work_to_pixel(p, work);
-        if (gid < 0) continue;
-        float *px = p.image + 3 * (size_t)gid;
-        f3 mean = mk3(0, 0, 0);
-        if (p.spp_begin > 0 && !p.raw_sample) mean = mk3(px[0], px[1], px[2]);
-        for (int s = p.spp_begin; s < p.spp_end; s++) {
-            f3 c = trace_path(p, gid, s, stack, stride, n_primary, n_bounce);
-            n_paths++;
-            int it = s + 1;
-            if (it == 1 || p.raw_sample) mean = c;
-            else {
-                float i1 = 1.0f / (float)it;
-                float i2 = (float)(it - 1) / (float)it;
-                mean = mk3((i1 * c.x) + (i2 * mean.x), (i1 * c.y) + (i2 * mean.y), (i1 * c.z) + (i2 * mean.z));
+
+    bool exhausted = false;              // no pixel and none left to fetch
+    int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path (camera ray)
+    uint32_t key = 0, ctr = 0;
+    f3 mean = mk3(0, 0, 0), color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+    Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
+    f3 inv = mk3(0, 0, 0);
+    bool nx = false, ny = false, nz = false;
+    float t = 1000.0f;
+    int hit = HPT_HIT_MISS;
+    int cur = HPT_REF_DONE, sp = 0, tri_next = 0, tri_end = 0;
+
+    auto set_cur = [&](int ref) {        // ref: interior index, packed leaf, or HPT_REF_DONE
+        if (ref < 0) { int packed = ~ref; tri_next = packed >> 6; tri_end = tri_next + (packed & 63) + 1; cur = HPT_CUR_LEAF; }
+        else cur = ref;
+    };
+    auto pop = [&]() {                   // deferred far-child test: tmin < t with the CURRENT t
+        int ref = HPT_REF_DONE;
+        while (sp > 0) {
+            sp--;
+            uint2 e = stack[sp * stride];
+            if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
+        }
+        set_cur(ref);
+    };
+
+    for (;;) {
+        const bool wantS = !exhausted && cur == HPT_REF_DONE;
+        const bool wantN = cur >= 0 && cur != HPT_REF_DONE;
+        const bool wantT = cur == HPT_CUR_LEAF;
+        const int nS = __popcll(__ballot(wantS)), nN = __popcll(__ballot(wantN)), nT = __popcll(__ballot(wantT));
+        if (nS + nN + nT == 0) break;
+
+        if (nS >= HPT_SHADE_THRESHOLD || nN + nT == 0) {
+            if (wantS) {
+                if (b >= 0) {            // a ray has just finished: one bounce of the path loop
+                    if (b == 0) n_primary++; else n_bounce++;
+                    bool go_on = shade_bounce(p, hit, t, r, key, ctr, b, color, weight);
+                    b++;
+                    if (!go_on || b >= p.max_depth) {
+                        mean = fold_sample(mean, color, s + 1, p.raw_sample != 0);
+                        n_paths++;
+                        s++;
+                        b = -1;
+                        if (s >= p.spp_end) {
+                            float *px = p.image + 3 * (size_t)gid;
+                            px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
+                            gid = -1;
+                        }
+                    }
+                }
+                if (gid < 0) {           // next pixel of this shard
+                    for (;;) {
+                        unsigned work = atomicAdd(p.work_counter, 1u);
+                        if (work >= p.n_work) { exhausted = true; break; }
+                        gid = work_to_pixel(p, work);
+                        if (gid >= 0) break;
+                    }
+                    if (!exhausted) {
+                        s = p.spp_begin;
+                        mean = mk3(0, 0, 0);
+                        if (p.spp_begin > 0 && !p.raw_sample) {
+                            const float *px = p.image + 3 * (size_t)gid;
+                            mean = mk3(px[0], px[1], px[2]);
+                        }
+                    }
+                }
+                if (!exhausted) {
+                    if (b < 0) {         // camera ray of (pixel, sample)
+                        key = path_key(p.seed, (uint32_t)gid, (uint32_t)s);
+                        ctr = 0;
+                        r = camera_ray(p, gid, s, key, ctr);
+                        color = mk3(0, 0, 0); weight = mk3(1, 1, 1);
+                        b = 0;
+                    }
+                    // start the closest-hit query of r: primitives first, then the tree (ray_kernel.cl:726-745)
+                    t = 1000.0f;
+                    hit = HPT_HIT_MISS;
+                    for (int i = 0; i < p.n_prims; i++)
+                        if (intersect_prim(p.prims + i, r.o, r.d, t)) hit = HPT_HIT_PRIMITIVE(i);
+                    sp = 0;
+                    cur = HPT_REF_DONE;
+                    if (p.root_ref != HPT_REF_DONE) {
+                        inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                        nx = inv.x < 0.0f; ny = inv.y < 0.0f; nz = inv.z < 0.0f;
+                        float tm;
+                        bool ok = slab(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
+                                       r.o, inv, nx, ny, nz, tm);
+                        if (ok && tm < t) set_cur(p.root_ref);
+                    }
+                }
+            }
+        } else if (nT > nN) {
+            if (wantT) {                 // one triangle of the current leaf
+                if (intersect_tri(p.tris, tri_next, r.o, r.d, t)) hit = tri_next;
+                tri_next++;
+                if (tri_next >= tri_end) pop();
+            }
+        } else {
+            if (wantN) {                 // one interior node: both children
+                const float4 *q = reinterpret_cast<const float4 *>(p.nodes + cur);
+                float4 a = q[0], bq = q[1], c = q[2];
+                int4 m = *reinterpret_cast<const int4 *>(q + 3);
+                float t0, t1;
+                bool ok0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, bq.x, bq.y), r.o, inv, nx, ny, nz, t0);
+                bool ok1 = slab(mk3(bq.z, bq.w, c.x), mk3(c.y, c.z, c.w), r.o, inv, nx, ny, nz, t1);
+                bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
+                bool second_first = (m.z == 0) ? nx : ((m.z == 1) ? ny : nz);       // dirIsNeg[axis], ray_kernel.cl:440
+                int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
+                bool hN = second_first ? h1 : h0, hF = second_first ? h0 : h1;
+                float tF = second_first ? t0 : t1;
+                if (hN) {
+                    if (hF) { stack[sp * stride] = make_uint2((unsigned)refF, __float_as_uint(tF)); sp++; }
+                    set_cur(refN);
+                } else if (hF) set_cur(refF);
+                else pop();
             }
         }
-        px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
     }
     atomicAdd(p.counters + 0, (unsigned long long)n_primary);
     atomicAdd(p.counters + 1, (unsigned long long)n_bounce);
