@@ -14,6 +14,9 @@ HOSTFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I/opt/rocm/include
 CFLAGS_ORACLE = -O2 -std=c11 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -Wall
 
 LIB_SRC = pathtracer_amd/csrc/hpt_backend.hip
+# kernel A/B builds: make variant EXTRA="-DFOO=1" OUT=build/libhpt_foo.so
+EXTRA ?=
+OUT ?= build/libhpt_variant.so
 HOST_SRC = pathtracer_amd/csrc/host/bvh.cpp pathtracer_amd/csrc/host/obj_reader.cpp \
            pathtracer_amd/csrc/host/image_writer.cpp pathtracer_amd/csrc/host/pathtracer.cpp \
            pathtracer_amd/csrc/host/host_capi.cpp
@@ -32,6 +35,11 @@ pathtracer_amd/csrc/hpt_backend.o: $(LIB_SRC) $(wildcard pathtracer_amd/csrc/*.h
 pathtracer_amd/libhpt.so: pathtracer_amd/csrc/hpt_backend.o $(HOST_OBJ)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC pathtracer_amd/csrc/hpt_backend.o $(HOST_OBJ) -o $@
 
+variant: $(HOST_OBJ)
+	mkdir -p $(dir $(OUT))
+	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(LIB_SRC) -o $(OUT).o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OUT).o $(HOST_OBJ) -o $(OUT)
+
 oracle: oracle/libpt_oracle.so
 oracle/libpt_oracle.so: oracle/pt_oracle.c oracle/pt_oracle.h include/hpt/types.h
 	$(CC) $(CFLAGS_ORACLE) -shared oracle/pt_oracle.c -o $@ -lm
@@ -43,4 +51,4 @@ scenes/libhpt_scenes.so: scenes/scenes.c
 clean:
 	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o
 
-.PHONY: all lib oracle scenes clean
+.PHONY: all lib oracle scenes clean variant

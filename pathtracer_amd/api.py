@@ -13,7 +13,7 @@ import numpy as np
 from .types import BBOX, CAMERA, INFO, MATERIAL, PRIMITIVE, TRIANGLE, Config, Stats
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhpt.so")
+LIB_PATH = os.environ.get("HPT_LIB") or os.path.join(_HERE, "libhpt.so")   # HPT_LIB: kernel A/B builds (bench/ab.py)
 _LIB = None
 
 # every symbol include/hpt/hpt.h declares

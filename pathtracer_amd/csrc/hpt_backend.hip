@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@ std::string g_create_error;
 
 constexpr int kMaxTreeDepth = 64;   // the reference's own bound: int todo[64], ray_kernel.cl:389
 constexpr int kBlock = 256;
+#define HPT_N_COUNTERS 16
 
 struct Buffer {
     void *ptr = nullptr;
@@ -65,6 +67,10 @@ struct hpt_ctx {
     bool timed = false;
     int n_cu = 256;
     int grid_waves = 0;
+    int shade_threshold = 20;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
+    int tris_per_trip = 8;
+    int node_repeat_min = 24;
+    int blocks_per_cu_cap = 0;       // 0 = occupancy limit (HPT_BLOCKS_PER_CU overrides)
     std::string err;
 };
 
@@ -133,6 +139,9 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     if (local_tiles < 0) local_tiles = 0;
     p.n_work = (uint32_t)local_tiles * 64u;
     p.raw_sample = raw;
+    p.shade_threshold = ctx->shade_threshold;
+    p.tris_per_trip = ctx->tris_per_trip;
+    p.node_repeat_min = ctx->node_repeat_min;
     return HPT_OK;
 }
 
@@ -148,7 +157,7 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
         return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     size_t lds = stack_lds_bytes(ctx, kBlock);
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent grid: as many blocks as stay resident (LDS stack and VGPRs bound it), at most the work
@@ -156,6 +165,7 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
     if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: tree depth %d needs %zu B of LDS",
                                 ctx->tree_depth, lds);
+    if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
     long blocks = (long)per_cu * ctx->n_cu;
     long need = ((long)p.n_work + kBlock - 1) / kBlock;
     if (blocks > need) blocks = need;
@@ -196,14 +206,18 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
+    if (const char *e = getenv("HPT_SHADE_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_threshold = v; }
+    if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
+    if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
+    if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
     size_t img = (size_t)width * height * 3 * sizeof(float);
     if ((e = hipMalloc((void **)&ctx->d_work, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void **)&ctx->d_counters, 3 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&ctx->d_counters, HPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_sample, img)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_accum, img)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_hit_id, (size_t)width * height * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_hit_t, (size_t)width * height * 4)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     *out = ctx;
@@ -469,9 +483,14 @@ int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats) {
     if (!stats) return HPT_ERR_INVALID;
     memset(stats, 0, sizeof *stats);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long c[3];
+    unsigned long long c[HPT_N_COUNTERS];
     HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
     stats->rays_primary = c[0]; stats->rays_bounce = c[1]; stats->paths = c[2];
+#ifdef HPT_PROFILE_STEPS
+    fprintf(stderr, "[hpt profile] trips S/T/N %llu %llu %llu  lane-active S/T/N %llu %llu %llu  util %.3f %.3f %.3f\n",
+            c[3] / 64, c[4] / 64, c[5] / 64, c[6], c[7], c[8], c[3] ? (double)c[6] / c[3] : 0.0, c[4] ? (double)c[7] / c[4] : 0.0,
+            c[5] ? (double)c[8] / c[5] : 0.0);
+#endif
     if (ctx->timed) {
         float ms = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));

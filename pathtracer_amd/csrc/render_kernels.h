@@ -52,6 +52,9 @@ struct RenderParams {
     int32_t tiles_x, n_tiles;
     uint32_t n_work;                 // local work items = local tiles * 64
     int32_t raw_sample;              // 1: store the sample itself (kernel_execute), 0: running mean
+    int32_t shade_threshold;         // lanes that must want SHADE before the wave runs it (scheduling only)
+    int32_t tris_per_trip;           // triangles a TRI step may test before the wave re-votes (scheduling only)
+    int32_t node_repeat_min;         // a NODE step repeats while this many lanes still want it (scheduling only; > 64 = never)
 };
 
 struct Ray { f3 o, d; };
@@ -100,23 +103,27 @@ __device__ __forceinline__ bool slab(f3 lo, f3 hi, f3 o, f3 inv, bool nx, bool n
 }
 
 // ---- Moller-Trumbore, ray_kernel.cl:467-520 ----
+// Straight-line form: every quantity is computed as the reference computes it when it gets that
+// far, and the reference's early returns become one conjunction (a value the reference never
+// reaches cannot change the outcome, and NaN comparisons keep their reference polarity).
 __device__ __forceinline__ bool intersect_tri(const float4 *__restrict__ tris, int idx, f3 o, f3 d, float &t) {
     const float4 *q = tris + 3 * (size_t)idx;
     float4 v1 = q[0], e1 = q[1], e2 = q[2];
     f3 edge1 = mk3(e1), edge2 = mk3(e2);
     f3 pvec = cross3(d, edge2);
     float det = dot3(edge1, pvec);
-    if (fabsf(det) < HPT_EPSILON) return false;
+    bool ok = !(fabsf(det) < HPT_EPSILON);
     float invDet = 1.0f / det;
     f3 tvec = o - mk3(v1);
     float u = dot3(tvec, pvec) * invDet;
-    if (u < 0.0f || u > 1.0f) return false;
+    ok = ok && !(u < 0.0f || u > 1.0f);
     f3 qvec = cross3(tvec, edge1);
     float v = dot3(d, qvec) * invDet;
-    if (v < 0.0f || u + v > 1.0f) return false;
+    ok = ok && !(v < 0.0f || u + v > 1.0f);
     float tt = dot3(edge2, qvec) * invDet;
-    if (tt < t && tt > 0.0f) { t = tt; return true; }
-    return false;
+    ok = ok && (tt < t && tt > 0.0f);
+    if (ok) t = tt;
+    return ok;
 }
 
 // ---- sphere / plane, ray_kernel.cl:524-602 ----
@@ -338,10 +345,6 @@ __device__ __forceinline__ f3 fold_sample(f3 mean, f3 c, int it, bool raw) {
     return mk3((i1 * c.x) + (i2 * mean.x), (i1 * c.y) + (i2 * mean.y), (i1 * c.z) + (i2 * mean.z));
 }
 
-#define HPT_CUR_LEAF (-1)
-#ifndef HPT_SHADE_THRESHOLD
-#define HPT_SHADE_THRESHOLD 20
-#endif
 
 // Persistent wavefront render kernel.
 //
@@ -353,28 +356,31 @@ __device__ __forceinline__ f3 fold_sample(f3 mean, f3 c, int it, bool raw) {
 // its lanes per state with three 64-bit ballots and executes ONE step kind, chosen wave-uniformly
 // (scalar branch): a lane never waits for another lane's longer traversal, longer path or longer
 // leaf, which is what held the one-path-per-lane form at 12 % lane utilisation (profiles/r01_v1_naive).
-// SHADE is the expensive, rare step, so it waits until HPT_SHADE_THRESHOLD lanes want it or nothing
+// SHADE is the expensive, rare step, so it waits until p.shade_threshold lanes want it or nothing
 // else is runnable.  Work order per lane is unchanged, so results stay bit-identical to the oracle.
 __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;
+#ifdef HPT_PROFILE_STEPS
+    unsigned long long prof_it[3] = {0, 0, 0}, prof_act[3] = {0, 0, 0};
+#endif
 
-    bool exhausted = false;              // no pixel and none left to fetch
+    // lane flags kept as bits of one VGPR (loop-carried bools would live as 64-bit lane masks that the
+    // compiler re-merges with scalar ops at every control-flow join): 1,2,4 = dirIsNeg x,y,z; 8 = exhausted
+    // (no pixel and none left to fetch)
+    unsigned flags = 0;
     int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path (camera ray)
     uint32_t key = 0, ctr = 0;
     f3 mean = mk3(0, 0, 0), color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
     f3 inv = mk3(0, 0, 0);
-    bool nx = false, ny = false, nz = false;
     float t = 1000.0f;
     int hit = HPT_HIT_MISS;
-    int cur = HPT_REF_DONE, sp = 0, tri_next = 0, tri_end = 0;
+    // cur: >= 0 interior node to test; < 0 leaf, ~cur = (next triangle << 6) | (triangles left - 1);
+    // HPT_REF_DONE: traversal over
+    int cur = HPT_REF_DONE, sp = 0;
 
-    auto set_cur = [&](int ref) {        // ref: interior index, packed leaf, or HPT_REF_DONE
-        if (ref < 0) { int packed = ~ref; tri_next = packed >> 6; tri_end = tri_next + (packed & 63) + 1; cur = HPT_CUR_LEAF; }
-        else cur = ref;
-    };
     auto pop = [&]() {                   // deferred far-child test: tmin < t with the CURRENT t
         int ref = HPT_REF_DONE;
         while (sp > 0) {
@@ -382,17 +388,24 @@ __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
             uint2 e = stack[sp * stride];
             if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
         }
-        set_cur(ref);
+        cur = ref;
     };
 
     for (;;) {
-        const bool wantS = !exhausted && cur == HPT_REF_DONE;
+        const bool wantS = !(flags & 8u) && cur == HPT_REF_DONE;
         const bool wantN = cur >= 0 && cur != HPT_REF_DONE;
-        const bool wantT = cur == HPT_CUR_LEAF;
+        const bool wantT = cur < 0;
         const int nS = __popcll(__ballot(wantS)), nN = __popcll(__ballot(wantN)), nT = __popcll(__ballot(wantT));
         if (nS + nN + nT == 0) break;
+#ifdef HPT_PROFILE_STEPS
+        {   // development build: per-kind trips and active lanes (bench/ab.py prints them)
+            int kind = (nS >= p.shade_threshold || nN + nT == 0) ? 0 : ((nT > nN) ? 1 : 2);
+            prof_it[kind]++;
+            if ((kind == 0 && wantS) || (kind == 1 && wantT) || (kind == 2 && wantN)) prof_act[kind]++;
+        }
+#endif
 
-        if (nS >= HPT_SHADE_THRESHOLD || nN + nT == 0) {
+        if (nS >= p.shade_threshold || nN + nT == 0) {
             if (wantS) {
                 if (b >= 0) {            // a ray has just finished: one bounce of the path loop
                     if (b == 0) n_primary++; else n_bounce++;
@@ -413,11 +426,11 @@ __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
                 if (gid < 0) {           // next pixel of this shard
                     for (;;) {
                         unsigned work = atomicAdd(p.work_counter, 1u);
-                        if (work >= p.n_work) { exhausted = true; break; }
+                        if (work >= p.n_work) { flags |= 8u; break; }
                         gid = work_to_pixel(p, work);
                         if (gid >= 0) break;
                     }
-                    if (!exhausted) {
+                    if (!(flags & 8u)) {
                         s = p.spp_begin;
                         mean = mk3(0, 0, 0);
                         if (p.spp_begin > 0 && !p.raw_sample) {
@@ -426,7 +439,7 @@ __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
                         }
                     }
                 }
-                if (!exhausted) {
+                if (!(flags & 8u)) {
                     if (b < 0) {         // camera ray of (pixel, sample)
                         key = path_key(p.seed, (uint32_t)gid, (uint32_t)s);
                         ctr = 0;
@@ -443,44 +456,63 @@ __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
                     cur = HPT_REF_DONE;
                     if (p.root_ref != HPT_REF_DONE) {
                         inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-                        nx = inv.x < 0.0f; ny = inv.y < 0.0f; nz = inv.z < 0.0f;
+                        const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+                        flags = (flags & ~7u) | (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                         float tm;
                         bool ok = slab(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
                                        r.o, inv, nx, ny, nz, tm);
-                        if (ok && tm < t) set_cur(p.root_ref);
+                        if (ok && tm < t) cur = p.root_ref;
                     }
                 }
             }
         } else if (nT > nN) {
-            if (wantT) {                 // one triangle of the current leaf
-                if (intersect_tri(p.tris, tri_next, r.o, r.d, t)) hit = tri_next;
-                tri_next++;
-                if (tri_next >= tri_end) pop();
+            // up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a leaf)
+            bool act = wantT;
+            for (int k = 0; k < p.tris_per_trip; k++) {
+                if (act) {
+                    const int packed = ~cur, idx = packed >> 6;
+                    if (intersect_tri(p.tris, idx, r.o, r.d, t)) hit = idx;
+                    if ((packed & 63) == 0) pop();
+                    else cur = ~(packed + 63);                  // next triangle, one fewer left
+                    act = cur < 0;
+                }
+                if (!__any(act)) break;
             }
         } else {
-            if (wantN) {                 // one interior node: both children
-                const float4 *q = reinterpret_cast<const float4 *>(p.nodes + cur);
-                float4 a = q[0], bq = q[1], c = q[2];
-                int4 m = *reinterpret_cast<const int4 *>(q + 3);
-                float t0, t1;
-                bool ok0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, bq.x, bq.y), r.o, inv, nx, ny, nz, t0);
-                bool ok1 = slab(mk3(bq.z, bq.w, c.x), mk3(c.y, c.z, c.w), r.o, inv, nx, ny, nz, t1);
-                bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
-                bool second_first = (m.z == 0) ? nx : ((m.z == 1) ? ny : nz);       // dirIsNeg[axis], ray_kernel.cl:440
-                int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
-                bool hN = second_first ? h1 : h0, hF = second_first ? h0 : h1;
-                float tF = second_first ? t0 : t1;
-                if (hN) {
-                    if (hF) { stack[sp * stride] = make_uint2((unsigned)refF, __float_as_uint(tF)); sp++; }
-                    set_cur(refN);
-                } else if (hF) set_cur(refF);
-                else pop();
+            // interior nodes: both children per step; the wave stays here, without a full re-vote, while at
+            // least node_repeat_min lanes still have an interior node to test
+            bool act = wantN;
+            for (;;) {
+                if (act) {
+                    const float4 *q = reinterpret_cast<const float4 *>(p.nodes + cur);
+                    float4 a = q[0], bq = q[1], c = q[2];
+                    int4 m = *reinterpret_cast<const int4 *>(q + 3);
+                    float t0, t1;
+                    const bool nx = flags & 1u, ny = flags & 2u, nz = flags & 4u;
+                    bool ok0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, bq.x, bq.y), r.o, inv, nx, ny, nz, t0);
+                    bool ok1 = slab(mk3(bq.z, bq.w, c.x), mk3(c.y, c.z, c.w), r.o, inv, nx, ny, nz, t1);
+                    bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
+                    bool second_first = (m.z == 0) ? nx : ((m.z == 1) ? ny : nz);       // dirIsNeg[axis], ray_kernel.cl:440
+                    int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
+                    bool hN = second_first ? h1 : h0, hF = second_first ? h0 : h1;
+                    float tF = second_first ? t0 : t1;
+                    if (hN) {
+                        if (hF) { stack[sp * stride] = make_uint2((unsigned)refF, __float_as_uint(tF)); sp++; }
+                        cur = refN;
+                    } else if (hF) cur = refF;
+                    else pop();
+                    act = cur >= 0 && cur != HPT_REF_DONE;
+                }
+                if (__popcll(__ballot(act)) < p.node_repeat_min) break;
             }
         }
     }
     atomicAdd(p.counters + 0, (unsigned long long)n_primary);
     atomicAdd(p.counters + 1, (unsigned long long)n_bounce);
     atomicAdd(p.counters + 2, (unsigned long long)n_paths);
+#ifdef HPT_PROFILE_STEPS
+    for (int k = 0; k < 3; k++) { atomicAdd(p.counters + 3 + k, prof_it[k]); atomicAdd(p.counters + 6 + k, prof_act[k]); }
+#endif
 }
 
 // closest hit of the camera ray, one lane per pixel (test hook)
