@@ -70,6 +70,9 @@ struct hpt_ctx {
     int shade_threshold = 20;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
     int tris_per_trip = 8;
     int node_repeat_min = 24;
+    int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
+    uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
+    size_t spill_bytes = 0;
     int blocks_per_cu_cap = 0;       // 0 = occupancy limit (HPT_BLOCKS_PER_CU overrides)
     std::string err;
 };
@@ -158,7 +161,9 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
         return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
-    size_t lds = stack_lds_bytes(ctx, kBlock);
+    const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
+    const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
+    size_t lds = (size_t)cap * kBlock * sizeof(uint2);
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent grid: as many blocks as stay resident (LDS stack and VGPRs bound it), at most the work
     int per_cu = 0;
@@ -171,6 +176,15 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     ctx->grid_waves = (int)(blocks * (kBlock / 64));
+    p.stack_cap = cap;
+    p.spill_stride = (uint32_t)(blocks * kBlock);
+    size_t spill_need = (size_t)(depth - cap) * p.spill_stride * sizeof(uint2);
+    if (spill_need > ctx->spill_bytes) {
+        if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_spill, spill_need));
+        ctx->spill_bytes = spill_need;
+    }
+    p.spill = ctx->d_spill;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
@@ -209,6 +223,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_SHADE_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_threshold = v; }
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
+    if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
     size_t img = (size_t)width * height * 3 * sizeof(float);
     if ((e = hipMalloc((void **)&ctx->d_work, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
@@ -229,7 +244,7 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
-    (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t);
+    (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

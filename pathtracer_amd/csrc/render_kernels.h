@@ -55,6 +55,9 @@ struct RenderParams {
     int32_t shade_threshold;         // lanes that must want SHADE before the wave runs it (scheduling only)
     int32_t tris_per_trip;           // triangles a TRI step may test before the wave re-votes (scheduling only)
     int32_t node_repeat_min;         // a NODE step repeats while this many lanes still want it (scheduling only; > 64 = never)
+    int32_t stack_cap;               // traversal-stack entries kept in LDS per lane; deeper entries go to `spill`
+    uint2 *spill;                    // [entry - stack_cap][grid lane], HBM; only touched by rays deeper than stack_cap
+    uint32_t spill_stride;           // lanes in the grid
 };
 
 struct Ray { f3 o, d; };
@@ -358,7 +361,11 @@ __device__ __forceinline__ f3 fold_sample(f3 mean, f3 c, int it, bool raw) {
 // leaf, which is what held the one-path-per-lane form at 12 % lane utilisation (profiles/r01_v1_naive).
 // SHADE is the expensive, rare step, so it waits until p.shade_threshold lanes want it or nothing
 // else is runnable.  Work order per lane is unchanged, so results stay bit-identical to the oracle.
-__global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
+// 6 waves/SIMD (<= 80 VGPRs): measured best; 7 and 8 spill to scratch and lose (profiles/r01_tuning.md)
+#ifndef HPT_MIN_WAVES
+#define HPT_MIN_WAVES 6
+#endif
+__global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;
@@ -381,11 +388,21 @@ __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
     // HPT_REF_DONE: traversal over
     int cur = HPT_REF_DONE, sp = 0;
 
+    // Stack entry e of this lane: LDS while e < stack_cap (the common case: near-first descent keeps few far
+    // children pending), HBM beyond.  Keeping only the shallow part in LDS is what lets more waves stay resident.
+    uint2 *const spill = p.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    auto push = [&](uint2 e) {
+        if (sp < p.stack_cap) stack[sp * stride] = e;
+        else spill[(size_t)(sp - p.stack_cap) * p.spill_stride] = e;
+        sp++;
+    };
     auto pop = [&]() {                   // deferred far-child test: tmin < t with the CURRENT t
         int ref = HPT_REF_DONE;
         while (sp > 0) {
             sp--;
-            uint2 e = stack[sp * stride];
+            uint2 e;
+            if (sp < p.stack_cap) e = stack[sp * stride];
+            else e = spill[(size_t)(sp - p.stack_cap) * p.spill_stride];
             if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
         }
         cur = ref;
@@ -497,7 +514,7 @@ __global__ void __launch_bounds__(256) render_kernel(const RenderParams p) {
                     bool hN = second_first ? h1 : h0, hF = second_first ? h0 : h1;
                     float tF = second_first ? t0 : t1;
                     if (hN) {
-                        if (hF) { stack[sp * stride] = make_uint2((unsigned)refF, __float_as_uint(tF)); sp++; }
+                        if (hF) push(make_uint2((unsigned)refF, __float_as_uint(tF)));
                         cur = refN;
                     } else if (hF) cur = refF;
                     else pop();

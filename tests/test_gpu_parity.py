@@ -119,6 +119,23 @@ def test_config_diffuse_scale_depth_and_rr():
         assert mismatch(be.kernel_execute(2), o2.kernel_execute(2)[0]) == 0
 
 
+@pytest.mark.parametrize("env", [dict(HPT_STACK_CAP="1"), dict(HPT_STACK_CAP="3", HPT_SHADE_THRESHOLD="1"),
+                                 dict(HPT_SHADE_THRESHOLD="64", HPT_TRIS_PER_TRIP="1", HPT_NODE_REPEAT_MIN="65"),
+                                 dict(HPT_TRIS_PER_TRIP="64", HPT_NODE_REPEAT_MIN="1", HPT_BLOCKS_PER_CU="1")])
+def test_scheduling_knobs_do_not_change_results(env, monkeypatch):
+    """The wave scheduler's knobs (which step kind runs, how long, how much of the traversal stack sits in
+    LDS before it overflows to HBM) only reorder work between lanes: every image stays bit-exact.
+    HPT_STACK_CAP=1 pushes almost every stack entry through the HBM overflow path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, kw in [("sponza", dict(width=96, height=54)), ("random", dict(n=2000, seed=1, width=64, height=64))]:
+        s, bvh, o = get_scene(name, **kw)
+        be = backend_for(s, bvh)
+        d = dev_image(be)
+        be.render(0, 3, d.data_ptr()); be.synchronize()
+        assert mismatch(d.cpu().numpy(), o.render(0, 3)[0]) == 0
+
+
 @pytest.mark.parametrize("w,h,world", [(64, 64, 2), (100, 52, 3), (72, 40, 8)])
 def test_tile_shards_reassemble_bit_exact(w, h, world):
     """Each shard renders only its 8x8 tiles; pack -> (all-gather) -> unpack gives the 1-GPU image."""
