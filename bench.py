@@ -80,10 +80,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # HPT_DIST_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then share devices)
+    dist_backend = os.environ.get("HPT_DIST_BACKEND", "nccl")
+    if dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     scn = scenes.scene(args.scene)
     spp = args.spp or scn["spp"]
@@ -125,7 +132,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([elapsed, float(rays_p), float(rays_b), sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([elapsed, float(rays_p), float(rays_b), sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64,
+                       device="cuda" if dist_backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)

@@ -67,7 +67,12 @@ def gather_image(backend, image, world, group=None):
     backend.pack_tiles(image.data_ptr(), slab.data_ptr())
     # the pack kernel runs on the backend's stream; the collective on torch's current stream
     backend.synchronize()
-    dist.all_gather_into_tensor(slabs, slab, group=group)
+    if dist.get_backend(group) == "gloo":           # rehearsal on a box with fewer GPUs than ranks: stage through the host
+        parts = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, slab.cpu(), group=group)
+        slabs.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(slabs, slab, group=group)
     torch.cuda.current_stream().synchronize()
     backend.unpack_tiles(slabs.data_ptr(), image.data_ptr())
     backend.synchronize()
