@@ -297,6 +297,11 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
         return HPT_OK;
     };
 
+    for (int k = 0; k < n_nodes; k++) {          // lo <= hi, no NaN: the min3/max3 slab test relies on it
+        const hpt_bvh_bbox &b = bbox[k];
+        if (!(b.minboundsx <= b.maxboundsx && b.minboundsy <= b.maxboundsy && b.minboundsz <= b.maxboundsz))
+            return fail(ctx, HPT_ERR_BVH, "node %d: bounding box with min > max or NaN", k);
+    }
     // pass 1: walk the tree from node 0, number interior nodes in pre-order, validate
     std::vector<int> wide_of(n_nodes, -1);
     std::vector<unsigned char> seen(n_nodes, 0);

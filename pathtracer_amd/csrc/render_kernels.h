@@ -105,6 +105,32 @@ __device__ __forceinline__ bool slab(f3 lo, f3 hi, f3 o, f3 inv, bool nx, bool n
     return !rej && (tmax > HPT_EPSILON);
 }
 
+// The same test with min3/max3 (v_max3_f32 / v_min3_f32) instead of compare+select chains.
+// Equivalence with the form above, NaNs included (DESIGN.md §Slab test):
+//  * a NaN on the x axis stays in tmin or tmax to the end in the reference (every later comparison with it is
+//    false), so the box is neither hit nor pushed: `nanx` forces that outcome;
+//  * a NaN on y or z is skipped by the reference (`tymin > tmin`, `tymax < tmax` are false, as are the reject
+//    comparisons it appears in) and skipped by maxNum/minNum, so tmin and tmax come out the same;
+//  * with the x values finite, "some near_i > far_j, i != j" (the reference's four reject comparisons) is
+//    "max of nears > min of fars", because near_i <= far_i on each axis for a box with lo <= hi
+//    (hpt_upload_bvh rejects others): fp32 subtract and multiply are monotone.
+// Only the sign of a zero tmin can differ (maxNum(-0,+0) = +0), which no comparison with t > 0 sees.
+__device__ __forceinline__ bool slab_minmax(f3 lo, f3 hi, f3 o, f3 inv, bool nx, bool ny, bool nz, float &tmin_out) {
+    float txn = ((nx ? hi.x : lo.x) - o.x) * inv.x, txf = ((nx ? lo.x : hi.x) - o.x) * inv.x;
+    float tyn = ((ny ? hi.y : lo.y) - o.y) * inv.y, tyf = ((ny ? lo.y : hi.y) - o.y) * inv.y;
+    float tzn = ((nz ? hi.z : lo.z) - o.z) * inv.z, tzf = ((nz ? lo.z : hi.z) - o.z) * inv.z;
+    bool nanx = __builtin_isunordered(txn, txf);
+    float tmin = __builtin_fmaxf(__builtin_fmaxf(txn, tyn), tzn);
+    float tmax = __builtin_fminf(__builtin_fminf(txf, tyf), tzf);
+    tmin_out = tmin;
+    return !nanx && !(tmin > tmax) && (tmax > HPT_EPSILON);
+}
+#ifdef HPT_SLAB_REFFORM
+#define HPT_SLAB slab
+#else
+#define HPT_SLAB slab_minmax
+#endif
+
 // ---- Moller-Trumbore, ray_kernel.cl:467-520 ----
 // Straight-line form: every quantity is computed as the reference computes it when it gets that
 // far, and the reference's early returns become one conjunction (a value the reference never
@@ -391,19 +417,30 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
     // Stack entry e of this lane: LDS while e < stack_cap (the common case: near-first descent keeps few far
     // children pending), HBM beyond.  Keeping only the shallow part in LDS is what lets more waves stay resident.
     uint2 *const spill = p.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    // The LDS-only forms run when no active lane of the wave is past stack_cap (a wave-uniform test, so the
+    // common case has plain ds_write/ds_read and no generic-pointer select).
     auto push = [&](uint2 e) {
-        if (sp < p.stack_cap) stack[sp * stride] = e;
+        if (!__any(sp >= p.stack_cap)) stack[sp * stride] = e;
+        else if (sp < p.stack_cap) stack[sp * stride] = e;
         else spill[(size_t)(sp - p.stack_cap) * p.spill_stride] = e;
         sp++;
     };
     auto pop = [&]() {                   // deferred far-child test: tmin < t with the CURRENT t
         int ref = HPT_REF_DONE;
-        while (sp > 0) {
-            sp--;
-            uint2 e;
-            if (sp < p.stack_cap) e = stack[sp * stride];
-            else e = spill[(size_t)(sp - p.stack_cap) * p.spill_stride];
-            if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
+        if (!__any(sp > p.stack_cap)) {
+            while (sp > 0) {
+                sp--;
+                uint2 e = stack[sp * stride];
+                if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
+            }
+        } else {
+            while (sp > 0) {
+                sp--;
+                uint2 e;
+                if (sp < p.stack_cap) e = stack[sp * stride];
+                else e = spill[(size_t)(sp - p.stack_cap) * p.spill_stride];
+                if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
+            }
         }
         cur = ref;
     };
@@ -476,7 +513,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
                         flags = (flags & ~7u) | (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                         float tm;
-                        bool ok = slab(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
+                        bool ok = HPT_SLAB(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
                                        r.o, inv, nx, ny, nz, tm);
                         if (ok && tm < t) cur = p.root_ref;
                     }
@@ -506,13 +543,16 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                     int4 m = *reinterpret_cast<const int4 *>(q + 3);
                     float t0, t1;
                     const bool nx = flags & 1u, ny = flags & 2u, nz = flags & 4u;
-                    bool ok0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, bq.x, bq.y), r.o, inv, nx, ny, nz, t0);
-                    bool ok1 = slab(mk3(bq.z, bq.w, c.x), mk3(c.y, c.z, c.w), r.o, inv, nx, ny, nz, t1);
+                    bool ok0 = HPT_SLAB(mk3(a.x, a.y, a.z), mk3(a.w, bq.x, bq.y), r.o, inv, nx, ny, nz, t0);
+                    bool ok1 = HPT_SLAB(mk3(bq.z, bq.w, c.x), mk3(c.y, c.z, c.w), r.o, inv, nx, ny, nz, t1);
                     bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
-                    bool second_first = (m.z == 0) ? nx : ((m.z == 1) ? ny : nz);       // dirIsNeg[axis], ray_kernel.cl:440
+                    const bool second_first = (flags >> m.z) & 1u;                     // dirIsNeg[axis], ray_kernel.cl:440
                     int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
-                    bool hN = second_first ? h1 : h0, hF = second_first ? h0 : h1;
                     float tF = second_first ? t0 : t1;
+                    // near/far hit flags as 64-bit lane-mask arithmetic (scalar ops) instead of per-lane selects
+                    const unsigned long long M0 = __ballot(h0), M1 = __ballot(h1), SF = __ballot(second_first);
+                    const bool hN = __builtin_amdgcn_inverse_ballot_w64((M1 & SF) | (M0 & ~SF));
+                    const bool hF = __builtin_amdgcn_inverse_ballot_w64((M0 & SF) | (M1 & ~SF));
                     if (hN) {
                         if (hF) push(make_uint2((unsigned)refF, __float_as_uint(tF)));
                         cur = refN;
