@@ -73,6 +73,9 @@ struct hpt_ctx {
     int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
     size_t spill_bytes = 0;
+    float *d_samples = nullptr;      // [iteration in batch][pixel slot][3] radiance samples of one launch
+    size_t samples_bytes = 0;
+    size_t sample_budget_bytes = (size_t)8 << 30;   // HPT_SAMPLE_BUDGET_MB overrides; bounds iterations per launch
     int blocks_per_cu_cap = 0;       // 0 = occupancy limit (HPT_BLOCKS_PER_CU overrides)
     std::string err;
 };
@@ -140,7 +143,9 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     p.tiles_x = tiles_x(ctx); p.n_tiles = n_tiles(ctx);
     int local_tiles = (p.n_tiles - ctx->rank + ctx->world - 1) / ctx->world;
     if (local_tiles < 0) local_tiles = 0;
-    p.n_work = (uint32_t)local_tiles * 64u;
+    p.n_slots = (uint32_t)local_tiles * 64u;
+    p.n_work = p.n_slots;
+    p.batch = 1; p.spp_base = spp_begin;
     p.raw_sample = raw;
     p.shade_threshold = ctx->shade_threshold;
     p.tris_per_trip = ctx->tris_per_trip;
@@ -153,14 +158,34 @@ size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
     return (size_t)depth * block * sizeof(uint2);
 }
 
+// One render = one or more launches of render_kernel (each over a batch of iterations whose samples fit the
+// sample buffer) each followed by fold_kernel.
 int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int raw) {
     RenderParams p;
     int rc = fill_params(ctx, p, d_image, spp_begin, spp_end, raw);
     if (rc) return rc;
     if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
         return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    ctx->timed = false;
+    if (p.n_slots == 0) return HPT_OK;
+
+    // iterations per launch: bounded by the sample buffer budget and by 32-bit work indices
+    const size_t bytes_per_iteration = (size_t)p.n_slots * 3 * sizeof(float);
+    long batch_max = (long)(ctx->sample_budget_bytes / bytes_per_iteration);
+    const long idx_max = (long)(0xFFFFFF00u / p.n_slots);
+    if (batch_max > idx_max) batch_max = idx_max;
+    if (batch_max < 1) batch_max = 1;
+    const int total = spp_end - spp_begin;
+    const int batch_alloc = total < batch_max ? total : (int)batch_max;
+    const size_t samples_need = bytes_per_iteration * (size_t)batch_alloc;
+    if (samples_need > ctx->samples_bytes) {
+        if (ctx->d_samples) { HIP_TRY(ctx, hipFree(ctx->d_samples)); ctx->d_samples = nullptr; ctx->samples_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_samples, samples_need));
+        ctx->samples_bytes = samples_need;
+    }
+    p.samples = ctx->d_samples;
+
     const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
     const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
     size_t lds = (size_t)cap * kBlock * sizeof(uint2);
@@ -168,27 +193,38 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     // persistent grid: as many blocks as stay resident (LDS stack and VGPRs bound it), at most the work
     int per_cu = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
-    if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: tree depth %d needs %zu B of LDS",
-                                ctx->tree_depth, lds);
+    if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: %zu B of LDS per block", lds);
     if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
-    long blocks = (long)per_cu * ctx->n_cu;
-    long need = ((long)p.n_work + kBlock - 1) / kBlock;
-    if (blocks > need) blocks = need;
-    if (blocks < 1) blocks = 1;
-    ctx->grid_waves = (int)(blocks * (kBlock / 64));
+    const long blocks_max = (long)per_cu * ctx->n_cu;
     p.stack_cap = cap;
-    p.spill_stride = (uint32_t)(blocks * kBlock);
-    size_t spill_need = (size_t)(depth - cap) * p.spill_stride * sizeof(uint2);
+    size_t spill_need = (size_t)(depth - cap) * (size_t)(blocks_max * kBlock) * sizeof(uint2);
     if (spill_need > ctx->spill_bytes) {
         if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_spill, spill_need));
         ctx->spill_bytes = spill_need;
     }
     p.spill = ctx->d_spill;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+
+    const bool single = total <= batch_alloc;     // then the events bracket render_kernel alone
+    if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int base = spp_begin; base < spp_end; base += batch_alloc) {
+        p.spp_base = base;
+        p.batch = (spp_end - base) < batch_alloc ? (spp_end - base) : batch_alloc;
+        p.n_work = p.n_slots * (uint32_t)p.batch;
+        long blocks = blocks_max;
+        long need = ((long)p.n_work + kBlock - 1) / kBlock;
+        if (blocks > need) blocks = need;
+        ctx->grid_waves = (int)(blocks * (kBlock / 64));
+        p.spill_stride = (uint32_t)(blocks * kBlock);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
+        if (single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
+        HIP_TRY(ctx, hipGetLastError());
+        if (single) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        hipLaunchKernelGGL(fold_kernel, dim3((p.n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, p);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
     return HPT_OK;
 }
@@ -223,6 +259,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_SHADE_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_threshold = v; }
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
+    if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
     if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
     size_t img = (size_t)width * height * 3 * sizeof(float);
@@ -244,7 +281,7 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
-    (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill);
+    (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -58,6 +58,10 @@ struct RenderParams {
     int32_t stack_cap;               // traversal-stack entries kept in LDS per lane; deeper entries go to `spill`
     uint2 *spill;                    // [entry - stack_cap][grid lane], HBM; only touched by rays deeper than stack_cap
     uint32_t spill_stride;           // lanes in the grid
+    float *samples;                  // [batch sample][slot][3]: one radiance sample per (pixel, iteration) of this launch
+    uint32_t n_slots;                // pixel slots of this shard = local tiles * 64
+    int32_t batch;                   // iterations in this launch: spp_base .. spp_base + batch - 1
+    int32_t spp_base;
 };
 
 struct Ray { f3 o, d; };
@@ -377,16 +381,21 @@ __device__ __forceinline__ f3 fold_sample(f3 mean, f3 c, int it, bool raw) {
 
 // Persistent wavefront render kernel.
 //
-// Every lane owns one pixel at a time and carries that pixel's running mean in registers over its
-// samples (so samples fold in iteration order whatever the grid or the shard).  A lane is always
-// in one of three states: NODE (an interior two-child node to test), TRI (a leaf with triangles
-// left, one per step) or SHADE (its ray's traversal is over: shade, Russian roulette, next ray /
-// next sample / next pixel from the global work counter).  Each trip of the loop the wave counts
-// its lanes per state with three 64-bit ballots and executes ONE step kind, chosen wave-uniformly
-// (scalar branch): a lane never waits for another lane's longer traversal, longer path or longer
-// leaf, which is what held the one-path-per-lane form at 12 % lane utilisation (profiles/r01_v1_naive).
-// SHADE is the expensive, rare step, so it waits until p.shade_threshold lanes want it or nothing
-// else is runnable.  Work order per lane is unchanged, so results stay bit-identical to the oracle.
+// Work item = one path: (pixel slot, iteration).  Items are numbered tile-major, then iteration, then pixel
+// in the 8x8 tile, so the lanes that fetch together get coherent camera rays, and any number of lanes (or
+// GPUs) shares a frame without a tail: a pixel's samples are NOT tied to one lane.  Each finished path
+// stores its radiance sample to `samples`; fold_kernel then folds a pixel's samples in iteration order
+// (the running mean of pathtracer.cpp:200-217 is order-dependent in fp32), so the image is bit-identical
+// whatever the grid, the schedule or the shard.
+//
+// A lane is always in one of three states: NODE (an interior two-child node to test), TRI (a leaf with
+// triangles left) or SHADE (its ray's traversal is over: shade, Russian roulette, next ray or next path
+// from the global work counter).  Each trip of the loop the wave counts its lanes per state with three
+// 64-bit ballots and executes ONE step kind, chosen wave-uniformly (scalar branch): a lane never waits for
+// another lane's longer traversal, longer path or longer leaf, which is what held the one-path-per-lane
+// form at 12 % lane utilisation (profiles/r01_v1_naive).  SHADE is the expensive, rare step, so it waits
+// until p.shade_threshold lanes want it or nothing else is runnable.  Work order per path is unchanged,
+// so results stay bit-identical to the oracle.
 // 6 waves/SIMD (<= 80 VGPRs): measured best; 7 and 8 spill to scratch and lose (profiles/r01_tuning.md)
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 6
@@ -401,11 +410,12 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 
     // lane flags kept as bits of one VGPR (loop-carried bools would live as 64-bit lane masks that the
     // compiler re-merges with scalar ops at every control-flow join): 1,2,4 = dirIsNeg x,y,z; 8 = exhausted
-    // (no pixel and none left to fetch)
+    // (no path and none left to fetch)
     unsigned flags = 0;
-    int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path (camera ray)
+    int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path
+    unsigned out_idx = 0;                // sample slot of the current path: (s - spp_base) * n_slots + pixel slot
     uint32_t key = 0, ctr = 0;
-    f3 mean = mk3(0, 0, 0), color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+    f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
     Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
     f3 inv = mk3(0, 0, 0);
     float t = 1000.0f;
@@ -466,35 +476,24 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                     bool go_on = shade_bounce(p, hit, t, r, key, ctr, b, color, weight);
                     b++;
                     if (!go_on || b >= p.max_depth) {
-                        mean = fold_sample(mean, color, s + 1, p.raw_sample != 0);
+                        float *o = p.samples + 3 * (size_t)out_idx;
+                        o[0] = color.x; o[1] = color.y; o[2] = color.z;
                         n_paths++;
-                        s++;
                         b = -1;
-                        if (s >= p.spp_end) {
-                            float *px = p.image + 3 * (size_t)gid;
-                            px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
-                            gid = -1;
-                        }
                     }
                 }
-                if (gid < 0) {           // next pixel of this shard
+                if (b < 0) {             // next path of this shard: (tile, iteration, pixel in tile)
                     for (;;) {
                         unsigned work = atomicAdd(p.work_counter, 1u);
                         if (work >= p.n_work) { flags |= 8u; break; }
-                        gid = work_to_pixel(p, work);
-                        if (gid >= 0) break;
-                    }
-                    if (!(flags & 8u)) {
-                        s = p.spp_begin;
-                        mean = mk3(0, 0, 0);
-                        if (p.spp_begin > 0 && !p.raw_sample) {
-                            const float *px = p.image + 3 * (size_t)gid;
-                            mean = mk3(px[0], px[1], px[2]);
-                        }
+                        const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
+                        const unsigned slot = tile * 64u + (work & 63u);
+                        gid = work_to_pixel(p, slot);
+                        if (gid >= 0) { s = p.spp_base + (int)sl; out_idx = sl * p.n_slots + slot; break; }
                     }
                 }
                 if (!(flags & 8u)) {
-                    if (b < 0) {         // camera ray of (pixel, sample)
+                    if (b < 0) {         // camera ray of (pixel, iteration)
                         key = path_key(p.seed, (uint32_t)gid, (uint32_t)s);
                         ctr = 0;
                         r = camera_ray(p, gid, s, key, ctr);
@@ -570,6 +569,24 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 #ifdef HPT_PROFILE_STEPS
     for (int k = 0; k < 3; k++) { atomicAdd(p.counters + 3 + k, prof_it[k]); atomicAdd(p.counters + 6 + k, prof_act[k]); }
 #endif
+}
+
+// Folds the samples of one launch into the running-mean image, one lane per pixel slot, iterations in
+// order: image = (1/it)*sample + ((it-1)/it)*image, it 1-based (pathtracer.cpp:200-217).  raw: the image
+// receives the sample itself (hpt_kernel_execute).  Streams samples once: batch*12 B read per pixel.
+__global__ void __launch_bounds__(256) fold_kernel(const RenderParams p) {
+    unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= p.n_slots) return;
+    int gid = work_to_pixel(p, slot);
+    if (gid < 0) return;
+    float *px = p.image + 3 * (size_t)gid;
+    f3 mean = mk3(0, 0, 0);
+    if (p.spp_base > 0 && !p.raw_sample) mean = mk3(px[0], px[1], px[2]);
+    for (int sl = 0; sl < p.batch; sl++) {
+        const float *c = p.samples + 3 * ((size_t)sl * p.n_slots + slot);
+        mean = fold_sample(mean, mk3(c[0], c[1], c[2]), p.spp_base + sl + 1, p.raw_sample != 0);
+    }
+    px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
 }
 
 // closest hit of the camera ray, one lane per pixel (test hook)
