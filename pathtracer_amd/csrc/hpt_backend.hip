@@ -67,9 +67,10 @@ struct hpt_ctx {
     bool timed = false;
     int n_cu = 256;
     int grid_waves = 0;
-    int shade_threshold = 20;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
+    int shade_threshold = 32;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
     int tris_per_trip = 8;
     int node_repeat_min = 24;
+    int fetch_chunk = 1;             // 1: lanes that fetch together get adjacent pixels (coherent camera rays); larger chunks lose (r01_tuning.md)
     int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
     size_t spill_bytes = 0;
@@ -150,6 +151,7 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     p.shade_threshold = ctx->shade_threshold;
     p.tris_per_trip = ctx->tris_per_trip;
     p.node_repeat_min = ctx->node_repeat_min;
+    p.fetch_chunk = ctx->fetch_chunk;
     return HPT_OK;
 }
 
@@ -260,6 +262,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
+    if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->fetch_chunk = v; }
     if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
     size_t img = (size_t)width * height * 3 * sizeof(float);

@@ -62,6 +62,7 @@ struct RenderParams {
     uint32_t n_slots;                // pixel slots of this shard = local tiles * 64
     int32_t batch;                   // iterations in this launch: spp_base .. spp_base + batch - 1
     int32_t spp_base;
+    int32_t fetch_chunk;             // work items a lane reserves per atomic (scheduling only)
 };
 
 struct Ray { f3 o, d; };
@@ -413,6 +414,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
     // (no path and none left to fetch)
     unsigned flags = 0;
     int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path
+    unsigned work_next = 0, work_left = 0;   // items this lane has reserved from the work counter
     unsigned out_idx = 0;                // sample slot of the current path: (s - spp_base) * n_slots + pixel slot
     uint32_t key = 0, ctr = 0;
     f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
@@ -484,8 +486,13 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                 }
                 if (b < 0) {             // next path of this shard: (tile, iteration, pixel in tile)
                     for (;;) {
-                        unsigned work = atomicAdd(p.work_counter, 1u);
+                        if (work_left == 0) {    // reserve fetch_chunk consecutive items with one atomic
+                            work_next = atomicAdd(p.work_counter, (unsigned)p.fetch_chunk);
+                            work_left = (unsigned)p.fetch_chunk;
+                        }
+                        const unsigned work = work_next;
                         if (work >= p.n_work) { flags |= 8u; break; }
+                        work_next++; work_left--;
                         const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
                         const unsigned slot = tile * 64u + (work & 63u);
                         gid = work_to_pixel(p, slot);
