@@ -136,6 +136,19 @@ def test_scheduling_knobs_do_not_change_results(env, monkeypatch):
         assert mismatch(d.cpu().numpy(), o.render(0, 3)[0]) == 0
 
 
+def test_sample_buffer_batches(monkeypatch):
+    """A render whose samples do not fit the sample buffer is split into several launches of render_kernel,
+    each folded in iteration order: same image.  1 MB holds 10 iterations of a 96x96 shard."""
+    monkeypatch.setenv("HPT_SAMPLE_BUDGET_MB", "1")
+    s, bvh, o = get_scene("cornell", width=96, height=96)
+    be = backend_for(s, bvh)
+    d = dev_image(be)
+    be.render(0, 23, d.data_ptr()); be.synchronize()
+    assert mismatch(d.cpu().numpy(), o.render(0, 23)[0]) == 0
+    st = be.stats()
+    assert st["paths"] == 23 * 96 * 96
+
+
 @pytest.mark.parametrize("w,h,world", [(64, 64, 2), (100, 52, 3), (72, 40, 8)])
 def test_tile_shards_reassemble_bit_exact(w, h, world):
     """Each shard renders only its 8x8 tiles; pack -> (all-gather) -> unpack gives the 1-GPU image."""
