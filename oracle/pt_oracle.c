@@ -197,6 +197,12 @@ int orc_intersect_prim(const float o[3], const float d[3], const hpt_primitive *
     return intersect_prim(V(o[0], o[1], o[2]), V(d[0], d[1], d[2]), p, t);
 }
 
+/* optional instrumentation for layout studies: visits per tree depth (not thread-safe: use n_threads=1) */
+static const int32_t *g_depth_table = NULL;
+static uint64_t g_depth_hist[64];
+void orc_set_depth_table(const int32_t *table) { g_depth_table = table; memset(g_depth_hist, 0, sizeof g_depth_hist); }
+void orc_get_depth_hist(uint64_t *out) { memcpy(out, g_depth_hist, sizeof g_depth_hist); }
+
 /* ---- BVH traversal: ray_kernel.cl:382-464 ---- */
 static int intersect_tri_bvh(const orc_scene *s, v3 o, v3 d, float *t, int *tri_id,
                              uint64_t *n_nodes, uint64_t *n_tris) {
@@ -210,6 +216,7 @@ static int intersect_tri_bvh(const orc_scene *s, v3 o, v3 d, float *t, int *tri_
         const hpt_bvh_bbox *bb = &s->bbox[nodeNum];
         const hpt_bvh_info *n = &s->info[nodeNum];
         (*n_nodes)++;
+        if (g_depth_table) g_depth_hist[g_depth_table[nodeNum] & 63]++;
         if (intersect_box(o, V(bb->minboundsx, bb->minboundsy, bb->minboundsz),
                           V(bb->maxboundsx, bb->maxboundsy, bb->maxboundsz), invDir, dirIsNeg, *t)) {
             if (n->nPrimitives > 0) {
