@@ -1,5 +1,6 @@
 # Builds everything in-tree (the .so files travel to the GPU box with the snapshot).
 #   make            -> product library + oracle + scene generator
+#   make cli        -> pathtracer_amd/hpt_cli             (g++)            headless viewer replacement
 #   make lib        -> pathtracer_amd/libhpt.so           (hipcc, gfx950)  the product
 #   make oracle     -> oracle/libpt_oracle.so             (gcc)            test infrastructure
 #   make scenes     -> scenes/libhpt_scenes.so            (gcc)            test/bench infrastructure
@@ -22,7 +23,7 @@ HOST_SRC = pathtracer_amd/csrc/host/bvh.cpp pathtracer_amd/csrc/host/obj_reader.
            pathtracer_amd/csrc/host/host_capi.cpp
 HOST_OBJ = $(HOST_SRC:.cpp=.o)
 
-all: lib oracle scenes
+all: lib cli oracle scenes
 
 lib: pathtracer_amd/libhpt.so
 
@@ -40,6 +41,10 @@ variant: $(HOST_OBJ)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(LIB_SRC) -o $(OUT).o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OUT).o $(HOST_OBJ) -o $(OUT)
 
+cli: pathtracer_amd/hpt_cli
+pathtracer_amd/hpt_cli: pathtracer_amd/csrc/host/hpt_cli.cpp pathtracer_amd/libhpt.so
+	$(CXX) $(HOSTFLAGS) pathtracer_amd/csrc/host/hpt_cli.cpp -o $@ -Lpathtracer_amd -lhpt -Wl,-rpath,'$$ORIGIN'
+
 oracle: oracle/libpt_oracle.so
 oracle/libpt_oracle.so: oracle/pt_oracle.c oracle/pt_oracle.h include/hpt/types.h
 	$(CC) $(CFLAGS_ORACLE) -shared oracle/pt_oracle.c -o $@ -lm
@@ -51,4 +56,4 @@ scenes/libhpt_scenes.so: scenes/scenes.c
 clean:
 	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o
 
-.PHONY: all lib oracle scenes clean variant
+.PHONY: all lib cli oracle scenes clean variant

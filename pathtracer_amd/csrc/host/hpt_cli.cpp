@@ -1,0 +1,85 @@
+// hpt_cli — headless replacement of the reference's GLUT viewer (reference pathtracer/main.cpp:57-223):
+// same sequence — new Pathtracer(w,h), load_obj, set_triangles, set_scene, set_camera, render loop, PNG out —
+// without a window.  The 'p' key of the viewer (main.cpp:194-203) becomes --out.
+//
+//   hpt_cli --obj model.obj [--w 100 --h 100] [--spp 16] [--depth 15] [--device 0] [--out image.png|.ppm]
+//           [--light cx cy cz radius intensity]   (adds an emissive sphere; triangles cannot emit)
+//           [--progressive]                       (one render() per sample, like the viewer's idle loop)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "image_writer.hpp"
+#include "obj_reader.hpp"
+#include "pathtracer.hpp"
+
+using namespace hpt;
+
+static hpt_float4 f4(float x, float y, float z, float w) { hpt_float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+int main(int argc, char **argv) {
+    std::string obj, out = "out.png";
+    int w = 100, h = 100, spp = 16, depth = 15, device = 0;      // window 100x100: main.cpp:41-42
+    bool progressive = false, have_light = false;
+    float light[5] = {0, -150, -40, 40, 10};
+    for (int i = 1; i < argc; i++) {
+        auto need = [&](int n) { if (i + n >= argc) { std::fprintf(stderr, "missing value after %s\n", argv[i]); std::exit(2); } };
+        if (!std::strcmp(argv[i], "--obj")) { need(1); obj = argv[++i]; }
+        else if (!std::strcmp(argv[i], "--out")) { need(1); out = argv[++i]; }
+        else if (!std::strcmp(argv[i], "--w")) { need(1); w = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--h")) { need(1); h = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--spp")) { need(1); spp = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--depth")) { need(1); depth = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--device")) { need(1); device = std::atoi(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--progressive")) progressive = true;
+        else if (!std::strcmp(argv[i], "--light")) { need(5); for (int k = 0; k < 5; k++) light[k] = (float)std::atof(argv[++i]); have_light = true; }
+        else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    if (obj.empty()) { std::fprintf(stderr, "usage: hpt_cli --obj model.obj [--w W --h H --spp N --depth D --out file.png --light cx cy cz r e --progressive]\n"); return 2; }
+
+    Pathtracer pt(w, h, device);
+    if (!pt.ok()) { std::fprintf(stderr, "hpt_cli: %s\n", pt.error()); return 1; }
+    std::vector<Vec3f> vertices;
+    if (!load_obj(obj.c_str(), vertices)) { std::fprintf(stderr, "hpt_cli: cannot read %s\n", obj.c_str()); return 1; }
+    auto t0 = std::chrono::steady_clock::now();
+    if (!pt.set_triangles(vertices)) { std::fprintf(stderr, "hpt_cli: set_triangles failed (%zu vertices; at least 12 triangles needed): %s\n", vertices.size(), pt.error()); return 1; }
+    double t_bvh = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (have_light) {
+        std::vector<hpt_material> mats(1);
+        std::memset(&mats[0], 0, sizeof mats[0]);
+        mats[0].refractive = f4(1, 0, 0, 0); mats[0].diffuse = f4(0.6f, 0.4f, 0.2f, 0);        // pathtracer.cpp:327-328
+        std::vector<hpt_primitive> prims(1);
+        std::memset(&prims[0], 0, sizeof prims[0]);
+        prims[0].refractive = f4(1, 0, 0, 0);
+        prims[0].center = f4(light[0], light[1], light[2], 0); prims[0].radius = light[3];
+        prims[0].emissive = f4(light[4], light[4], light[4], light[4]);
+        if (!pt.set_scene(prims, mats)) { std::fprintf(stderr, "hpt_cli: %s\n", pt.error()); return 1; }
+    } else if (!pt.set_scene()) { std::fprintf(stderr, "hpt_cli: %s\n", pt.error()); return 1; }
+    pt.set_camera();
+    hpt_config cfg{depth, 3, 2.0f, 0x5EEDu};
+    pt.set_config(cfg);
+
+    t0 = std::chrono::steady_clock::now();
+    Pixel *img = nullptr;
+    if (progressive) for (int s = 0; s < spp; s++) img = pt.render();
+    else img = pt.render(spp);
+    double t_render = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!img) { std::fprintf(stderr, "hpt_cli: render failed: %s\n", pt.error()); return 1; }
+
+    Bitmap bmp{img, w, h};
+    bool ppm = out.size() > 4 && out.compare(out.size() - 4, 4, ".ppm") == 0;
+    if ((ppm ? save_ppm_to_file(&bmp, out.c_str()) : save_png_to_file(&bmp, out.c_str())) != 0) {
+        std::fprintf(stderr, "hpt_cli: cannot write %s\n", out.c_str());
+        return 1;
+    }
+    hpt_stats st;
+    hpt_get_stats(pt.backend(), &st);
+    std::printf("{\"triangles\": %zu, \"width\": %d, \"height\": %d, \"spp\": %d, \"bvh_s\": %.4f, \"render_s\": %.4f, "
+                "\"rays_last_call\": %llu, \"out\": \"%s\"}\n",
+                vertices.size() / 3, w, h, pt.get_iterations(), t_bvh, t_render,
+                (unsigned long long)(st.rays_primary + st.rays_bounce), out.c_str());
+    return 0;
+}

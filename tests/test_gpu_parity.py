@@ -288,3 +288,36 @@ def test_full_size_properties_c3():
     for row in (3, 540, 1077):
         oimg, _ = o.render(0, 2, px_begin=row * w, px_end=(row + 1) * w)
         assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0
+
+
+def test_cli_obj_to_png_end_to_end(tmp_path):
+    """The headless replacement of main.cpp: OBJ file -> load_obj -> BVH build -> upload -> render -> PNG, all in the
+    C++ host side; the PNG must equal the oracle's image through the reference's 8-bit conversion."""
+    import os
+    import subprocess
+    from PIL import Image
+    from oracle import binding as orc
+    from conftest import ROOT
+    s, bvh, _ = get_scene("cornell", width=64, height=64)
+    v = s["verts"].reshape(-1, 3)
+    obj = tmp_path / "cornell.obj"
+    with open(obj, "w") as f:
+        f.write("# cornell-like test scene\n")
+        for x, y, z in v:
+            f.write("v %.9g %.9g %.9g\n" % (x, y, z))
+        for i in range(len(v) // 3):
+            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    out = tmp_path / "o.png"
+    light = (0.0, -52.0, 5.0, 16.0, 12.0)
+    for extra in ([], ["--progressive"]):
+        r = subprocess.run([os.path.join(ROOT, "pathtracer_amd", "hpt_cli"), "--obj", str(obj), "--w", "64", "--h", "64", "--spp", "3",
+                            "--depth", "4", "--out", str(out), "--light"] + [repr(x) for x in light] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        prims = scenes.sphere(light[:3], light[3], emissive=(light[4],) * 3)
+        cfg = dict(s["cfg"], max_depth=4)
+        o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], prims, scenes.make_material((0.6, 0.4, 0.2)),
+                            scenes.default_camera(), 64, 64, cfg)
+        want = orc.tonemap(o.render(0, 3)[0]).reshape(64, 64, 3)
+        got = np.asarray(Image.open(str(out)).convert("RGB"))
+        assert np.array_equal(got, want)
