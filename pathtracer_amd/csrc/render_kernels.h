@@ -17,15 +17,18 @@
 // 64-byte node: the boxes of both children of one interior node of the
 // reference tree (child0 = node k+1, child1 = secondChildOffset, bvh.cpp:382-386).
 // ref >= 0: index of the child's own WideNode; ref < 0: leaf, ~ref = (first triangle << 6) | (count-1).
+// Per axis one 16-B piece {lo of child 0, lo of child 1, hi of child 0, hi of child 1}: the two children's
+// plane distances come out of one v_pk_add_f32 + one v_pk_mul_f32 per register pair.
 struct __attribute__((aligned(64))) WideNode {
-    float lo0x, lo0y, lo0z, hi0x;
-    float hi0y, hi0z, lo1x, lo1y;
-    float lo1z, hi1x, hi1y, hi1z;
+    float lo0x, lo1x, hi0x, hi1x;
+    float lo0y, lo1y, hi0y, hi1y;
+    float lo0z, lo1z, hi0z, hi1z;
     int32_t ref0, ref1, axis, pad;
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be one 64-B line");
 
 #define HPT_REF_DONE 0x7fffffff
+#define HPT_REF_IDLE 0x7ffffffe     // render_kernel only: the lane has no path and none is left to fetch
 #define HPT_LEAF_MAX_PRIMS 64
 #define HPT_LEAF_REF(offset, n) (~(((offset) << 6) | ((n) - 1)))
 
@@ -136,6 +139,71 @@ __device__ __forceinline__ bool slab_minmax(f3 lo, f3 hi, f3 o, f3 inv, bool nx,
 #define HPT_SLAB slab_minmax
 #endif
 
+// lane mask of a predicate without the int round trip of __ballot() (v_cndmask + v_cmp per call)
+__device__ __forceinline__ unsigned long long hpt_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
+// Both children of a WideNode at once.  X, Y, Z = {lo child0, lo child1, hi child0, hi child1} per axis, so
+// (lo - o) * inv and (hi - o) * inv are one packed subtract and one packed multiply per register pair
+// (v_pk_add_f32 / v_pk_mul_f32: per component the same IEEE operations as the scalar form, no contraction).
+// The ray's origin and reciprocal direction travel as three register pairs {o.x,o.y} {o.z,inv.x} {inv.y,inv.z}
+// whose halves the packed instructions broadcast with op_sel.  Per child the arithmetic and the comparisons
+// are those of slab_minmax; the result is the lane mask of "box hit and tmin < t" per child, built from one
+// v_cmp per comparison and scalar ANDs.
+typedef float hpt_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab2_minmax(float4 X, float4 Y, float4 Z, hpt_v2f oxy, hpt_v2f ozix, hpt_v2f iyz,
+                                             bool nx, bool ny, bool nz, float t,
+                                             unsigned long long &M0, unsigned long long &M1, float &tmin0, float &tmin1) {
+#ifdef HPT_NO_PK_ASM
+    const hpt_v2f tlx = (hpt_v2f{X.x, X.y} - oxy.xx) * ozix.yy, thx = (hpt_v2f{X.z, X.w} - oxy.xx) * ozix.yy;
+    const hpt_v2f tly = (hpt_v2f{Y.x, Y.y} - oxy.yy) * iyz.xx, thy = (hpt_v2f{Y.z, Y.w} - oxy.yy) * iyz.xx;
+    const hpt_v2f tlz = (hpt_v2f{Z.x, Z.y} - ozix.xx) * iyz.yy, thz = (hpt_v2f{Z.z, Z.w} - ozix.xx) * iyz.yy;
+#else
+    // hipcc materialises each broadcast operand as its own register pair (12 VGPRs, which spill); written out,
+    // op_sel broadcasts the half of the ray pair in place.  a - b is a + (-b) (neg_lo/neg_hi on src1), exactly.
+    // (hipcc puts its own wait state after the block before the first use of a product.)
+    hpt_v2f tlx = {X.x, X.y}, thx = {X.z, X.w}, tly = {Y.x, Y.y}, thy = {Y.z, Y.w}, tlz = {Z.x, Z.y}, thz = {Z.z, Z.w};
+    asm("v_pk_add_f32 %0, %0, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %1, %6 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %2, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %3, %6 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %4, %4, %7 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %5, %5, %7 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %0, %0, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %1, %1, %7 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %2, %2, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %3, %3, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %4, %4, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %5, %5, %8 op_sel:[0,1] op_sel_hi:[1,1]"
+        : "+v"(tlx), "+v"(thx), "+v"(tly), "+v"(thy), "+v"(tlz), "+v"(thz)
+        : "v"(oxy), "v"(ozix), "v"(iyz));
+#endif
+    const hpt_v2f txn = nx ? thx : tlx, txf = nx ? tlx : thx;
+    const hpt_v2f tyn = ny ? thy : tly, tyf = ny ? tly : thy;
+    const hpt_v2f tzn = nz ? thz : tlz, tzf = nz ? tlz : thz;
+    tmin0 = __builtin_fmaxf(__builtin_fmaxf(txn.x, tyn.x), tzn.x);
+    tmin1 = __builtin_fmaxf(__builtin_fmaxf(txn.y, tyn.y), tzn.y);
+    const float tmax0 = __builtin_fminf(__builtin_fminf(txf.x, tyf.x), tzf.x);
+    const float tmax1 = __builtin_fminf(__builtin_fminf(txf.y, tyf.y), tzf.y);
+    M0 = hpt_ballot(!__builtin_isunordered(txn.x, txf.x)) & hpt_ballot(!(tmin0 > tmax0)) &
+         hpt_ballot(tmax0 > HPT_EPSILON) & hpt_ballot(tmin0 < t);
+    M1 = hpt_ballot(!__builtin_isunordered(txn.y, txf.y)) & hpt_ballot(!(tmin1 > tmax1)) &
+         hpt_ballot(tmax1 > HPT_EPSILON) & hpt_ballot(tmin1 < t);
+}
+__device__ __forceinline__ void slab2_refform(float4 X, float4 Y, float4 Z, hpt_v2f oxy, hpt_v2f ozix, hpt_v2f iyz,
+                                              bool nx, bool ny, bool nz, float t,
+                                              unsigned long long &M0, unsigned long long &M1, float &tmin0, float &tmin1) {
+    const f3 o = mk3(oxy.x, oxy.y, ozix.x), inv = mk3(ozix.y, iyz.x, iyz.y);
+    const bool ok0 = slab(mk3(X.x, Y.x, Z.x), mk3(X.z, Y.z, Z.z), o, inv, nx, ny, nz, tmin0);
+    const bool ok1 = slab(mk3(X.y, Y.y, Z.y), mk3(X.w, Y.w, Z.w), o, inv, nx, ny, nz, tmin1);
+    M0 = hpt_ballot(ok0 && tmin0 < t);
+    M1 = hpt_ballot(ok1 && tmin1 < t);
+}
+#ifdef HPT_SLAB_REFFORM
+#define HPT_SLAB2 slab2_refform
+#else
+#define HPT_SLAB2 slab2_minmax
+#endif
+
 // ---- Moller-Trumbore, ray_kernel.cl:467-520 ----
 // Straight-line form: every quantity is computed as the reference computes it when it gets that
 // far, and the reference's early returns become one conjunction (a value the reference never
@@ -216,8 +284,8 @@ __device__ __forceinline__ int traverse(const RenderParams &p, f3 o, f3 d, float
             float4 a = q[0], b = q[1], c = q[2];
             int4 m = *reinterpret_cast<const int4 *>(q + 3);
             float t0, t1;
-            bool ok0 = slab(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), o, inv, nx, ny, nz, t0);
-            bool ok1 = slab(mk3(b.z, b.w, c.x), mk3(c.y, c.z, c.w), o, inv, nx, ny, nz, t1);
+            bool ok0 = slab(mk3(a.x, b.x, c.x), mk3(a.z, b.z, c.z), o, inv, nx, ny, nz, t0);
+            bool ok1 = slab(mk3(a.y, b.y, c.y), mk3(a.w, b.w, c.w), o, inv, nx, ny, nz, t1);
             bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
             // near child first: dirIsNeg[axis] -> second child first (ray_kernel.cl:440-451)
             bool second_first = (m.z == 0) ? nx : ((m.z == 1) ? ny : nz);
@@ -410,58 +478,50 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 #endif
 
     // lane flags kept as bits of one VGPR (loop-carried bools would live as 64-bit lane masks that the
-    // compiler re-merges with scalar ops at every control-flow join): 1,2,4 = dirIsNeg x,y,z; 8 = exhausted
-    // (no path and none left to fetch)
+    // compiler re-merges with scalar ops at every control-flow join): 1,2,4 = dirIsNeg x,y,z
     unsigned flags = 0;
     int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path
     unsigned work_next = 0, work_left = 0;   // items this lane has reserved from the work counter
     unsigned out_idx = 0;                // sample slot of the current path: (s - spp_base) * n_slots + pixel slot
     uint32_t key = 0, ctr = 0;
     f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
-    Ray r; r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
-    f3 inv = mk3(0, 0, 0);
+    // ray: direction as three floats; origin and reciprocal direction as the register pairs of slab2_minmax
+    f3 rd = mk3(0, 0, 1);
+    hpt_v2f oxy = {0, 0}, ozix = {0, 0}, iyz = {0, 0};
     float t = 1000.0f;
     int hit = HPT_HIT_MISS;
     // cur: >= 0 interior node to test; < 0 leaf, ~cur = (next triangle << 6) | (triangles left - 1);
-    // HPT_REF_DONE: traversal over
+    // HPT_REF_DONE: traversal over (SHADE state); HPT_REF_IDLE: no path and none left to fetch.
+    // Each state is ONE comparison on cur, so its lane mask is one v_cmp.
     int cur = HPT_REF_DONE, sp = 0;
 
     // Stack entry e of this lane: LDS while e < stack_cap (the common case: near-first descent keeps few far
     // children pending), HBM beyond.  Keeping only the shallow part in LDS is what lets more waves stay resident.
     uint2 *const spill = p.spill + (blockIdx.x * blockDim.x + threadIdx.x);
-    // The LDS-only forms run when no active lane of the wave is past stack_cap (a wave-uniform test, so the
-    // common case has plain ds_write/ds_read and no generic-pointer select).
+    // Two independent predicated stores/loads (not an if/else that hipcc would merge into one flat access
+    // through a selected generic pointer); the HBM half is skipped by an execz branch in the common case.
     auto push = [&](uint2 e) {
-        if (!__any(sp >= p.stack_cap)) stack[sp * stride] = e;
-        else if (sp < p.stack_cap) stack[sp * stride] = e;
-        else spill[(size_t)(sp - p.stack_cap) * p.spill_stride] = e;
+        if (sp < p.stack_cap) stack[sp * stride] = e;
+        if (sp >= p.stack_cap) spill[(size_t)(sp - p.stack_cap) * p.spill_stride] = e;
         sp++;
     };
     auto pop = [&]() {                   // deferred far-child test: tmin < t with the CURRENT t
         int ref = HPT_REF_DONE;
-        if (!__any(sp > p.stack_cap)) {
-            while (sp > 0) {
-                sp--;
-                uint2 e = stack[sp * stride];
-                if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
-            }
-        } else {
-            while (sp > 0) {
-                sp--;
-                uint2 e;
-                if (sp < p.stack_cap) e = stack[sp * stride];
-                else e = spill[(size_t)(sp - p.stack_cap) * p.spill_stride];
-                if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
-            }
+        while (sp > 0) {
+            sp--;
+            uint2 e = make_uint2(0u, 0u);
+            if (sp < p.stack_cap) e = stack[sp * stride];
+            if (sp >= p.stack_cap) e = spill[(size_t)(sp - p.stack_cap) * p.spill_stride];
+            if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
         }
         cur = ref;
     };
 
     for (;;) {
-        const bool wantS = !(flags & 8u) && cur == HPT_REF_DONE;
-        const bool wantN = cur >= 0 && cur != HPT_REF_DONE;
+        const bool wantS = cur == HPT_REF_DONE;
+        const bool wantN = (unsigned)cur < (unsigned)HPT_REF_IDLE;
         const bool wantT = cur < 0;
-        const int nS = __popcll(__ballot(wantS)), nN = __popcll(__ballot(wantN)), nT = __popcll(__ballot(wantT));
+        const int nS = __popcll(hpt_ballot(wantS)), nN = __popcll(hpt_ballot(wantN)), nT = __popcll(hpt_ballot(wantT));
         if (nS + nN + nT == 0) break;
 #ifdef HPT_PROFILE_STEPS
         {   // development build: per-kind trips and active lanes (bench/ab.py prints them)
@@ -473,8 +533,10 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 
         if (nS >= p.shade_threshold || nN + nT == 0) {
             if (wantS) {
+                Ray r;
                 if (b >= 0) {            // a ray has just finished: one bounce of the path loop
                     if (b == 0) n_primary++; else n_bounce++;
+                    r.o = mk3(oxy.x, oxy.y, ozix.x); r.d = rd;
                     bool go_on = shade_bounce(p, hit, t, r, key, ctr, b, color, weight);
                     b++;
                     if (!go_on || b >= p.max_depth) {
@@ -491,7 +553,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                             work_left = (unsigned)p.fetch_chunk;
                         }
                         const unsigned work = work_next;
-                        if (work >= p.n_work) { flags |= 8u; break; }
+                        if (work >= p.n_work) { cur = HPT_REF_IDLE; break; }
                         work_next++; work_left--;
                         const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
                         const unsigned slot = tile * 64u + (work & 63u);
@@ -499,7 +561,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         if (gid >= 0) { s = p.spp_base + (int)sl; out_idx = sl * p.n_slots + slot; break; }
                     }
                 }
-                if (!(flags & 8u)) {
+                if (cur != HPT_REF_IDLE) {
                     if (b < 0) {         // camera ray of (pixel, iteration)
                         key = path_key(p.seed, (uint32_t)gid, (uint32_t)s);
                         ctr = 0;
@@ -514,8 +576,12 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         if (intersect_prim(p.prims + i, r.o, r.d, t)) hit = HPT_HIT_PRIMITIVE(i);
                     sp = 0;
                     cur = HPT_REF_DONE;
+                    rd = r.d;
+                    oxy = hpt_v2f{r.o.x, r.o.y};
+                    ozix.x = r.o.z;
                     if (p.root_ref != HPT_REF_DONE) {
-                        inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                        const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+                        ozix.y = inv.x; iyz = hpt_v2f{inv.y, inv.z};
                         const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
                         flags = (flags & ~7u) | (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
                         float tm;
@@ -527,36 +593,35 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
             }
         } else if (nT > nN) {
             // up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a leaf)
-            bool act = wantT;
+            // (a lane is in the TRI state exactly when cur < 0, so the state is re-read from cur, not carried)
             for (int k = 0; k < p.tris_per_trip; k++) {
-                if (act) {
+                if (cur < 0) {
                     const int packed = ~cur, idx = packed >> 6;
-                    if (intersect_tri(p.tris, idx, r.o, r.d, t)) hit = idx;
+                    if (intersect_tri(p.tris, idx, mk3(oxy.x, oxy.y, ozix.x), rd, t)) hit = idx;
                     if ((packed & 63) == 0) pop();
                     else cur = ~(packed + 63);                  // next triangle, one fewer left
-                    act = cur < 0;
                 }
-                if (!__any(act)) break;
+                if (hpt_ballot(cur < 0) == 0ull) break;
             }
         } else {
             // interior nodes: both children per step; the wave stays here, without a full re-vote, while at
             // least node_repeat_min lanes still have an interior node to test
-            bool act = wantN;
             for (;;) {
-                if (act) {
-                    const float4 *q = reinterpret_cast<const float4 *>(p.nodes + cur);
-                    float4 a = q[0], bq = q[1], c = q[2];
-                    int4 m = *reinterpret_cast<const int4 *>(q + 3);
-                    float t0, t1;
+                if ((unsigned)cur < (unsigned)HPT_REF_IDLE) {
+                    // 32-bit byte offset (n_wide < 2^25): saddr + voffset addressing, no 64-bit address math
+                    const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + ((unsigned)cur << 6));
+                    const float4 X = q[0], Y = q[1], Z = q[2];
+                    const int4 m = *reinterpret_cast<const int4 *>(q + 3);
                     const bool nx = flags & 1u, ny = flags & 2u, nz = flags & 4u;
-                    bool ok0 = HPT_SLAB(mk3(a.x, a.y, a.z), mk3(a.w, bq.x, bq.y), r.o, inv, nx, ny, nz, t0);
-                    bool ok1 = HPT_SLAB(mk3(bq.z, bq.w, c.x), mk3(c.y, c.z, c.w), r.o, inv, nx, ny, nz, t1);
-                    bool h0 = ok0 && (t0 < t), h1 = ok1 && (t1 < t);
-                    const bool second_first = (flags >> m.z) & 1u;                     // dirIsNeg[axis], ray_kernel.cl:440
-                    int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
-                    float tF = second_first ? t0 : t1;
-                    // near/far hit flags as 64-bit lane-mask arithmetic (scalar ops) instead of per-lane selects
-                    const unsigned long long M0 = __ballot(h0), M1 = __ballot(h1), SF = __ballot(second_first);
+                    float t0, t1;
+                    unsigned long long M0, M1;                    // lanes whose child 0 / child 1 is hit with tmin < t
+                    HPT_SLAB2(X, Y, Z, oxy, ozix, iyz, nx, ny, nz, t, M0, M1, t0, t1);
+                    // dirIsNeg[axis] (ray_kernel.cl:440): second child first.  Near/far hit flags are 64-bit
+                    // lane-mask arithmetic (scalar ops) instead of per-lane selects.
+                    const unsigned long long SF = hpt_ballot(((flags >> m.z) & 1u) != 0u);
+                    const bool second_first = __builtin_amdgcn_inverse_ballot_w64(SF);
+                    const int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
+                    const float tF = second_first ? t0 : t1;
                     const bool hN = __builtin_amdgcn_inverse_ballot_w64((M1 & SF) | (M0 & ~SF));
                     const bool hF = __builtin_amdgcn_inverse_ballot_w64((M0 & SF) | (M1 & ~SF));
                     if (hN) {
@@ -564,9 +629,8 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         cur = refN;
                     } else if (hF) cur = refF;
                     else pop();
-                    act = cur >= 0 && cur != HPT_REF_DONE;
                 }
-                if (__popcll(__ballot(act)) < p.node_repeat_min) break;
+                if (__popcll(hpt_ballot((unsigned)cur < (unsigned)HPT_REF_IDLE)) < p.node_repeat_min) break;
             }
         }
     }
