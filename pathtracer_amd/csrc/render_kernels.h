@@ -448,6 +448,108 @@ __device__ __forceinline__ f3 fold_sample(f3 mean, f3 c, int it, bool raw) {
 }
 
 
+// ---- per-lane traversal state of one ray and the two step kinds, shared by render_kernel and trace_kernel ----
+// cur: >= 0 interior node to test; < 0 leaf, ~cur = (next triangle << 6) | (triangles left - 1);
+// HPT_REF_DONE: traversal over; HPT_REF_IDLE: the lane has nothing left to do.  Each state is ONE comparison
+// on cur, so its lane mask is one v_cmp.
+struct Trav {
+    hpt_v2f oxy, ozix, iyz;      // {o.x,o.y} {o.z,inv.x} {inv.y,inv.z}: the register pairs of slab2_minmax
+    f3 rd;                       // direction (triangle tests, shading)
+    float t;
+    int hit, cur, sp;
+    unsigned flags;              // 1,2,4 = dirIsNeg x,y,z (bits of one VGPR, not loop-carried bools)
+};
+
+// Stack entry e of a lane: LDS while e < stack_cap (the common case: near-first descent keeps few far
+// children pending), HBM beyond.  Two independent predicated accesses (not an if/else that hipcc would merge
+// into one flat access through a selected generic pointer); the HBM half is skipped by an execz branch.
+__device__ __forceinline__ void trav_push(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill, uint2 e) {
+    if (s.sp < p.stack_cap) stack[s.sp * stride] = e;
+    if (s.sp >= p.stack_cap) spill[(size_t)(s.sp - p.stack_cap) * p.spill_stride] = e;
+    s.sp++;
+}
+// deferred far-child test: tmin < t with the CURRENT t
+__device__ __forceinline__ void trav_pop(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
+    int ref = HPT_REF_DONE;
+    while (s.sp > 0) {
+        s.sp--;
+        uint2 e = make_uint2(0u, 0u);
+        if (s.sp < p.stack_cap) e = stack[s.sp * stride];
+        if (s.sp >= p.stack_cap) e = spill[(size_t)(s.sp - p.stack_cap) * p.spill_stride];
+        if (__uint_as_float(e.y) < s.t) { ref = (int)e.x; break; }
+    }
+    s.cur = ref;
+}
+
+// TRI step: up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a
+// leaf).  A lane is in the TRI state exactly when cur < 0, so the state is re-read from cur, not carried.
+__device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
+    for (int k = 0; k < p.tris_per_trip; k++) {
+        if (s.cur < 0) {
+            const int packed = ~s.cur, idx = packed >> 6;
+            if (intersect_tri(p.tris, idx, mk3(s.oxy.x, s.oxy.y, s.ozix.x), s.rd, s.t)) s.hit = idx;
+            if ((packed & 63) == 0) trav_pop(p, s, stack, stride, spill);
+            else s.cur = ~(packed + 63);                  // next triangle, one fewer left
+        }
+        if (hpt_ballot(s.cur < 0) == 0ull) break;
+    }
+}
+
+// NODE step: both children per visit; the wave stays here, without a full re-vote, while at least
+// node_repeat_min lanes still have an interior node to test.
+__device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
+    for (;;) {
+        if ((unsigned)s.cur < (unsigned)HPT_REF_IDLE) {
+            // 32-bit byte offset (n_wide < 2^25): saddr + voffset addressing, no 64-bit address math
+            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + ((unsigned)s.cur << 6));
+            const float4 X = q[0], Y = q[1], Z = q[2];
+            const int4 m = *reinterpret_cast<const int4 *>(q + 3);
+            const bool nx = s.flags & 1u, ny = s.flags & 2u, nz = s.flags & 4u;
+            float t0, t1;
+            unsigned long long M0, M1;                    // lanes whose child 0 / child 1 is hit with tmin < t
+            HPT_SLAB2(X, Y, Z, s.oxy, s.ozix, s.iyz, nx, ny, nz, s.t, M0, M1, t0, t1);
+            // dirIsNeg[axis] (ray_kernel.cl:440): second child first.  Near/far hit flags are 64-bit
+            // lane-mask arithmetic (scalar ops) instead of per-lane selects.
+            const unsigned long long SF = hpt_ballot(((s.flags >> m.z) & 1u) != 0u);
+            const bool second_first = __builtin_amdgcn_inverse_ballot_w64(SF);
+            const int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
+            const float tF = second_first ? t0 : t1;
+            const bool hN = __builtin_amdgcn_inverse_ballot_w64((M1 & SF) | (M0 & ~SF));
+            const bool hF = __builtin_amdgcn_inverse_ballot_w64((M0 & SF) | (M1 & ~SF));
+            if (hN) {
+                if (hF) trav_push(p, s, stack, stride, spill, make_uint2((unsigned)refF, __float_as_uint(tF)));
+                s.cur = refN;
+            } else if (hF) s.cur = refF;
+            else trav_pop(p, s, stack, stride, spill);
+        }
+        if (__popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE)) < p.node_repeat_min) break;
+    }
+}
+
+// Starts the closest-hit query of ray (o, d): primitives first, then the tree (ray_kernel.cl:726-745).
+// Leaves cur = root reference, or HPT_REF_DONE when the root box is missed / there is no tree.
+__device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o, f3 d) {
+    s.t = 1000.0f;
+    s.hit = HPT_HIT_MISS;
+    for (int i = 0; i < p.n_prims; i++)
+        if (intersect_prim(p.prims + i, o, d, s.t)) s.hit = HPT_HIT_PRIMITIVE(i);
+    s.sp = 0;
+    s.cur = HPT_REF_DONE;
+    s.rd = d;
+    s.oxy = hpt_v2f{o.x, o.y};
+    s.ozix.x = o.z;
+    if (p.root_ref != HPT_REF_DONE) {
+        const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        s.ozix.y = inv.x; s.iyz = hpt_v2f{inv.y, inv.z};
+        const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+        s.flags = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+        float tm;
+        bool ok = HPT_SLAB(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
+                           o, inv, nx, ny, nz, tm);
+        if (ok && tm < s.t) s.cur = p.root_ref;
+    }
+}
+
 // Persistent wavefront render kernel.
 //
 // Work item = one path: (pixel slot, iteration).  Items are numbered tile-major, then iteration, then pixel
@@ -475,52 +577,23 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;
 #ifdef HPT_PROFILE_STEPS
     unsigned long long prof_it[3] = {0, 0, 0}, prof_act[3] = {0, 0, 0};
+    unsigned long long prof_waitS = 0, prof_idle = 0;     // per lane: trips spent waiting for SHADE / without work
 #endif
 
-    // lane flags kept as bits of one VGPR (loop-carried bools would live as 64-bit lane masks that the
-    // compiler re-merges with scalar ops at every control-flow join): 1,2,4 = dirIsNeg x,y,z
-    unsigned flags = 0;
     int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path
     unsigned work_next = 0, work_left = 0;   // items this lane has reserved from the work counter
     unsigned out_idx = 0;                // sample slot of the current path: (s - spp_base) * n_slots + pixel slot
     uint32_t key = 0, ctr = 0;
     f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
-    // ray: direction as three floats; origin and reciprocal direction as the register pairs of slab2_minmax
-    f3 rd = mk3(0, 0, 1);
-    hpt_v2f oxy = {0, 0}, ozix = {0, 0}, iyz = {0, 0};
-    float t = 1000.0f;
-    int hit = HPT_HIT_MISS;
-    // cur: >= 0 interior node to test; < 0 leaf, ~cur = (next triangle << 6) | (triangles left - 1);
-    // HPT_REF_DONE: traversal over (SHADE state); HPT_REF_IDLE: no path and none left to fetch.
-    // Each state is ONE comparison on cur, so its lane mask is one v_cmp.
-    int cur = HPT_REF_DONE, sp = 0;
-
-    // Stack entry e of this lane: LDS while e < stack_cap (the common case: near-first descent keeps few far
-    // children pending), HBM beyond.  Keeping only the shallow part in LDS is what lets more waves stay resident.
+    Trav tv;
+    tv.oxy = hpt_v2f{0, 0}; tv.ozix = hpt_v2f{0, 0}; tv.iyz = hpt_v2f{0, 0}; tv.rd = mk3(0, 0, 1);
+    tv.t = 1000.0f; tv.hit = HPT_HIT_MISS; tv.cur = HPT_REF_DONE; tv.sp = 0; tv.flags = 0;
     uint2 *const spill = p.spill + (blockIdx.x * blockDim.x + threadIdx.x);
-    // Two independent predicated stores/loads (not an if/else that hipcc would merge into one flat access
-    // through a selected generic pointer); the HBM half is skipped by an execz branch in the common case.
-    auto push = [&](uint2 e) {
-        if (sp < p.stack_cap) stack[sp * stride] = e;
-        if (sp >= p.stack_cap) spill[(size_t)(sp - p.stack_cap) * p.spill_stride] = e;
-        sp++;
-    };
-    auto pop = [&]() {                   // deferred far-child test: tmin < t with the CURRENT t
-        int ref = HPT_REF_DONE;
-        while (sp > 0) {
-            sp--;
-            uint2 e = make_uint2(0u, 0u);
-            if (sp < p.stack_cap) e = stack[sp * stride];
-            if (sp >= p.stack_cap) e = spill[(size_t)(sp - p.stack_cap) * p.spill_stride];
-            if (__uint_as_float(e.y) < t) { ref = (int)e.x; break; }
-        }
-        cur = ref;
-    };
 
     for (;;) {
-        const bool wantS = cur == HPT_REF_DONE;
-        const bool wantN = (unsigned)cur < (unsigned)HPT_REF_IDLE;
-        const bool wantT = cur < 0;
+        const bool wantS = tv.cur == HPT_REF_DONE;
+        const bool wantN = (unsigned)tv.cur < (unsigned)HPT_REF_IDLE;
+        const bool wantT = tv.cur < 0;
         const int nS = __popcll(hpt_ballot(wantS)), nN = __popcll(hpt_ballot(wantN)), nT = __popcll(hpt_ballot(wantT));
         if (nS + nN + nT == 0) break;
 #ifdef HPT_PROFILE_STEPS
@@ -528,6 +601,8 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
             int kind = (nS >= p.shade_threshold || nN + nT == 0) ? 0 : ((nT > nN) ? 1 : 2);
             prof_it[kind]++;
             if ((kind == 0 && wantS) || (kind == 1 && wantT) || (kind == 2 && wantN)) prof_act[kind]++;
+            if (kind != 0 && wantS) prof_waitS++;
+            if (tv.cur == HPT_REF_IDLE) prof_idle++;
         }
 #endif
 
@@ -536,8 +611,8 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                 Ray r;
                 if (b >= 0) {            // a ray has just finished: one bounce of the path loop
                     if (b == 0) n_primary++; else n_bounce++;
-                    r.o = mk3(oxy.x, oxy.y, ozix.x); r.d = rd;
-                    bool go_on = shade_bounce(p, hit, t, r, key, ctr, b, color, weight);
+                    r.o = mk3(tv.oxy.x, tv.oxy.y, tv.ozix.x); r.d = tv.rd;
+                    bool go_on = shade_bounce(p, tv.hit, tv.t, r, key, ctr, b, color, weight);
                     b++;
                     if (!go_on || b >= p.max_depth) {
                         float *o = p.samples + 3 * (size_t)out_idx;
@@ -553,7 +628,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                             work_left = (unsigned)p.fetch_chunk;
                         }
                         const unsigned work = work_next;
-                        if (work >= p.n_work) { cur = HPT_REF_IDLE; break; }
+                        if (work >= p.n_work) { tv.cur = HPT_REF_IDLE; break; }
                         work_next++; work_left--;
                         const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
                         const unsigned slot = tile * 64u + (work & 63u);
@@ -561,7 +636,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         if (gid >= 0) { s = p.spp_base + (int)sl; out_idx = sl * p.n_slots + slot; break; }
                     }
                 }
-                if (cur != HPT_REF_IDLE) {
+                if (tv.cur != HPT_REF_IDLE) {
                     if (b < 0) {         // camera ray of (pixel, iteration)
                         key = path_key(p.seed, (uint32_t)gid, (uint32_t)s);
                         ctr = 0;
@@ -569,69 +644,13 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         color = mk3(0, 0, 0); weight = mk3(1, 1, 1);
                         b = 0;
                     }
-                    // start the closest-hit query of r: primitives first, then the tree (ray_kernel.cl:726-745)
-                    t = 1000.0f;
-                    hit = HPT_HIT_MISS;
-                    for (int i = 0; i < p.n_prims; i++)
-                        if (intersect_prim(p.prims + i, r.o, r.d, t)) hit = HPT_HIT_PRIMITIVE(i);
-                    sp = 0;
-                    cur = HPT_REF_DONE;
-                    rd = r.d;
-                    oxy = hpt_v2f{r.o.x, r.o.y};
-                    ozix.x = r.o.z;
-                    if (p.root_ref != HPT_REF_DONE) {
-                        const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-                        ozix.y = inv.x; iyz = hpt_v2f{inv.y, inv.z};
-                        const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-                        flags = (flags & ~7u) | (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-                        float tm;
-                        bool ok = HPT_SLAB(mk3(p.root_lo[0], p.root_lo[1], p.root_lo[2]), mk3(p.root_hi[0], p.root_hi[1], p.root_hi[2]),
-                                       r.o, inv, nx, ny, nz, tm);
-                        if (ok && tm < t) cur = p.root_ref;
-                    }
+                    trav_start(p, tv, r.o, r.d);
                 }
             }
         } else if (nT > nN) {
-            // up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a leaf)
-            // (a lane is in the TRI state exactly when cur < 0, so the state is re-read from cur, not carried)
-            for (int k = 0; k < p.tris_per_trip; k++) {
-                if (cur < 0) {
-                    const int packed = ~cur, idx = packed >> 6;
-                    if (intersect_tri(p.tris, idx, mk3(oxy.x, oxy.y, ozix.x), rd, t)) hit = idx;
-                    if ((packed & 63) == 0) pop();
-                    else cur = ~(packed + 63);                  // next triangle, one fewer left
-                }
-                if (hpt_ballot(cur < 0) == 0ull) break;
-            }
+            trav_tri_steps(p, tv, stack, stride, spill);
         } else {
-            // interior nodes: both children per step; the wave stays here, without a full re-vote, while at
-            // least node_repeat_min lanes still have an interior node to test
-            for (;;) {
-                if ((unsigned)cur < (unsigned)HPT_REF_IDLE) {
-                    // 32-bit byte offset (n_wide < 2^25): saddr + voffset addressing, no 64-bit address math
-                    const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + ((unsigned)cur << 6));
-                    const float4 X = q[0], Y = q[1], Z = q[2];
-                    const int4 m = *reinterpret_cast<const int4 *>(q + 3);
-                    const bool nx = flags & 1u, ny = flags & 2u, nz = flags & 4u;
-                    float t0, t1;
-                    unsigned long long M0, M1;                    // lanes whose child 0 / child 1 is hit with tmin < t
-                    HPT_SLAB2(X, Y, Z, oxy, ozix, iyz, nx, ny, nz, t, M0, M1, t0, t1);
-                    // dirIsNeg[axis] (ray_kernel.cl:440): second child first.  Near/far hit flags are 64-bit
-                    // lane-mask arithmetic (scalar ops) instead of per-lane selects.
-                    const unsigned long long SF = hpt_ballot(((flags >> m.z) & 1u) != 0u);
-                    const bool second_first = __builtin_amdgcn_inverse_ballot_w64(SF);
-                    const int refN = second_first ? m.y : m.x, refF = second_first ? m.x : m.y;
-                    const float tF = second_first ? t0 : t1;
-                    const bool hN = __builtin_amdgcn_inverse_ballot_w64((M1 & SF) | (M0 & ~SF));
-                    const bool hF = __builtin_amdgcn_inverse_ballot_w64((M0 & SF) | (M1 & ~SF));
-                    if (hN) {
-                        if (hF) push(make_uint2((unsigned)refF, __float_as_uint(tF)));
-                        cur = refN;
-                    } else if (hF) cur = refF;
-                    else pop();
-                }
-                if (__popcll(hpt_ballot((unsigned)cur < (unsigned)HPT_REF_IDLE)) < p.node_repeat_min) break;
-            }
+            trav_node_steps(p, tv, stack, stride, spill);
         }
     }
     atomicAdd(p.counters + 0, (unsigned long long)n_primary);
@@ -639,6 +658,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
     atomicAdd(p.counters + 2, (unsigned long long)n_paths);
 #ifdef HPT_PROFILE_STEPS
     for (int k = 0; k < 3; k++) { atomicAdd(p.counters + 3 + k, prof_it[k]); atomicAdd(p.counters + 6 + k, prof_act[k]); }
+    atomicAdd(p.counters + 9, prof_waitS); atomicAdd(p.counters + 10, prof_idle);
 #endif
 }
 
