@@ -5,10 +5,12 @@
 // (reference pathtracer/bvh.hpp:59-73), and produces node and triangle ORDER
 // identical to the reference builder (bvh.cpp:141-390) including its quirks,
 // because hit order on ties depends on it.  The
-// implementation is its own: flat arrays, in-place counting sort per node,
-// nodes emitted straight into the depth-first arrays, no per-node allocations.
+// implementation is its own: flat arrays, counting sort per node, no per-node
+// allocations, and parallel over host threads (HPT_BUILD_THREADS, default
+// min(cores, 16)) with results identical to the sequential recursion.
 #pragma once
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "../../../include/hpt/types.h"
@@ -36,6 +38,20 @@ struct VectorTriangle {
     VectorTriangle(Vec3f a, Vec3f b, Vec3f c);
 };
 
+// host threads of the builder: min(cores, 16), HPT_BUILD_THREADS overrides
+int build_threads();
+
+// f(thread, begin, end) over [0, n) in contiguous chunks, one per thread (chunk order = thread order)
+template <class F>
+inline void parallel_chunks(int threads, long n, F f) {
+    if (threads <= 1 || n < 2) { f(0, 0L, n); return; }
+    std::vector<std::thread> th;
+    th.reserve(threads - 1);
+    for (int t = 1; t < threads; t++) th.emplace_back([=]() { f(t, n * t / threads, n * (t + 1) / threads); });
+    f(0, 0L, n / threads);
+    for (auto &x : th) x.join();
+}
+
 const int MAX_TRIANGLES_LEAF = 24;   // bvh.hpp:8
 const int NUM_BUCKETS = 12;          // bvh.hpp:9
 
@@ -56,7 +72,14 @@ public:
 
 private:
     struct Item { float mn[3], mx[3], c[3]; int32_t src; };
-    int build(int start, int end, int level);
+    struct Subtree {                       // nodes of one subtree in depth-first order, local indices
+        std::vector<hpt_bvh_bbox> bbox;
+        std::vector<hpt_bvh_info> info;
+        int depth = 0;
+    };
+    int build(Subtree &out, int start, int end, int level);
+    bool centroid_axis(int start, int end, int threads, int &axis, float &lo, double &span) const;
+    int partition_large(int start, int end, int threads);
     std::vector<VectorTriangle> vtriangles;
     std::vector<Item> items, scratch;
     std::vector<unsigned char> bucket;

@@ -16,12 +16,15 @@ extern "C" {
 // verts: n*9 floats. Outputs sized 2n-1 / 2n-1 / n / n. Returns n_nodes or -1 (n < 12).
 int hpt_host_build_bvh(const float *verts, int n, hpt_bvh_bbox *bbox, hpt_bvh_info *info, int32_t *order,
                        hpt_triangle *triangles, int *depth) {
-    std::vector<VectorTriangle> vt;
-    vt.reserve(n);
-    for (int i = 0; i < n; i++) {
-        const float *p = verts + 9 * (size_t)i;
-        vt.push_back(VectorTriangle(Vec3f(p[0], p[1], p[2]), Vec3f(p[3], p[4], p[5]), Vec3f(p[6], p[7], p[8])));
-    }
+    if (n < 0) return -1;
+    const int threads = build_threads();
+    std::vector<VectorTriangle> vt((size_t)n);
+    parallel_chunks(threads, n, [&](int, long b, long e) {
+        for (long i = b; i < e; i++) {
+            const float *p = verts + 9 * (size_t)i;
+            vt[i] = VectorTriangle(Vec3f(p[0], p[1], p[2]), Vec3f(p[3], p[4], p[5]), Vec3f(p[6], p[7], p[8]));
+        }
+    });
     BoundingVolumeHierarchy b(std::move(vt));
     if (!b.buildTree()) return -1;
     int nn = b.get_n_nodes();
@@ -30,13 +33,15 @@ int hpt_host_build_bvh(const float *verts, int n, hpt_bvh_bbox *bbox, hpt_bvh_in
     std::memcpy(order, b.get_order().data(), sizeof(int32_t) * (size_t)n);
     if (triangles) {
         const std::vector<VectorTriangle> &o = b.get_triangles();
-        for (int i = 0; i < n; i++) {                       // create_triangle, pathtracer.cpp:46-58
-            hpt_triangle &t = triangles[i];
-            const VectorTriangle &s = o[i];
-            t.v1.x = s.v1[0]; t.v1.y = s.v1[1]; t.v1.z = s.v1[2]; t.v1.w = 0;
-            t.e1.x = s.v2[0] - s.v1[0]; t.e1.y = s.v2[1] - s.v1[1]; t.e1.z = s.v2[2] - s.v1[2]; t.e1.w = 0;
-            t.e2.x = s.v3[0] - s.v1[0]; t.e2.y = s.v3[1] - s.v1[1]; t.e2.z = s.v3[2] - s.v1[2]; t.e2.w = 0;
-        }
+        parallel_chunks(threads, n, [&](int, long b, long e) {
+            for (long i = b; i < e; i++) {                  // create_triangle, pathtracer.cpp:46-58
+                hpt_triangle &t = triangles[i];
+                const VectorTriangle &s = o[i];
+                t.v1.x = s.v1[0]; t.v1.y = s.v1[1]; t.v1.z = s.v1[2]; t.v1.w = 0;
+                t.e1.x = s.v2[0] - s.v1[0]; t.e1.y = s.v2[1] - s.v1[1]; t.e1.z = s.v2[2] - s.v1[2]; t.e1.w = 0;
+                t.e2.x = s.v3[0] - s.v1[0]; t.e2.y = s.v3[1] - s.v1[1]; t.e2.z = s.v3[2] - s.v1[2]; t.e2.w = 0;
+            }
+        });
     }
     if (depth) *depth = b.get_depth();
     return nn;

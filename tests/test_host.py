@@ -34,6 +34,22 @@ def test_host_bvh_is_order_exact(name, kw):
     assert b["depth"] == depth.max()
 
 
+@pytest.mark.parametrize("threads,task_size", [(1, 0), (5, 25), (3, 100), (16, 4000)])
+@pytest.mark.parametrize("name,kw", [("random", dict(n=2000, seed=1)), ("degenerate", dict(n_same=200, n_other=30)), ("bunny", {})])
+def test_host_bvh_parallel_build_is_thread_invariant(monkeypatch, name, kw, threads, task_size):
+    """The parallel builder (top levels shared by threads, subtrees as tasks, the subtree holding global
+    positions 0..11 first) gives the sequential recursion's arrays whatever the thread count and task cut."""
+    s = scenes.scene(name, **kw)
+    ob, oi, oo = orc.build_bvh(s["verts"])
+    monkeypatch.setenv("HPT_BUILD_THREADS", str(threads))
+    if task_size:
+        monkeypatch.setenv("HPT_BUILD_TASK_SIZE", str(task_size))
+    b = api.build_bvh(s["verts"])
+    assert b["bbox"].tobytes() == ob.tobytes()
+    assert b["info"].tobytes() == oi.tobytes()
+    assert np.array_equal(b["order"], oo)
+
+
 def test_host_bvh_rejects_small_input():
     with pytest.raises(api.HptError):
         api.build_bvh(np.zeros((11, 3, 3), np.float32))
