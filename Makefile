@@ -9,8 +9,9 @@ CC    ?= gcc
 CXX   ?= g++
 
 # No FMA contraction, IEEE divide/sqrt: the numerics contract of DESIGN.md §Numerics.
+# No SLP vectorisation: hipcc packs the triangle test into v_pk ops glued by ~20 v_mov (2 % slower, more VGPRs).
 HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off \
-           -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Iinclude -Wall -Wno-unused-function
+           -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -Iinclude -Wall -Wno-unused-function
 HOSTFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Wall
 CFLAGS_ORACLE = -O2 -std=c11 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -Wall
 
