@@ -229,7 +229,12 @@ __device__ __forceinline__ bool intersect_tri(const float4 *__restrict__ tris, i
 }
 
 // ---- sphere / plane, ray_kernel.cl:524-602 ----
-__device__ __forceinline__ bool intersect_prim(const hpt_primitive *__restrict__ pr, f3 o, f3 d, float &t) {
+// The primitive index is wave-uniform wherever this is called (every lane walks the whole list), and the list
+// is read-only for the kernel's lifetime: read through the constant address space it becomes scalar loads
+// (s_load_dwordx4 into SGPRs, scalar branch on the type) instead of 64 identical vector loads.
+typedef const __attribute__((address_space(4))) hpt_primitive *hpt_prim_cptr;
+__device__ __forceinline__ bool intersect_prim(const hpt_primitive *prim, f3 o, f3 d, float &t) {
+    const hpt_prim_cptr pr = (hpt_prim_cptr)prim;
     float type = pr->type.x;
     if (type == 0.0f) {
         f3 oc = o - mk3(pr->center.x, pr->center.y, pr->center.z);
@@ -389,8 +394,12 @@ __device__ __forceinline__ bool shade_bounce(const RenderParams &p, int id, floa
         const float4 *q = p.tris + 3 * (size_t)id;
         normal = normalize3(cross3(mk3(q[1]), mk3(q[2])));
         if (dot3(normal, r.d) > 0.0f) normal = -normal;
-        const float4 *mm = reinterpret_cast<const float4 *>(p.mats);         // triangles use materials[0]
-        m.refractive = mm[0]; m.specular = mm[1]; m.diffuse = mm[2]; m.emissive = mm[3];
+        // triangles use materials[0]: one address for every lane, read with scalar loads
+        const __attribute__((address_space(4))) hpt_material *mm = (const __attribute__((address_space(4))) hpt_material *)p.mats;
+        m.refractive = make_float4(mm->refractive.x, mm->refractive.y, mm->refractive.z, mm->refractive.w);
+        m.specular = make_float4(mm->specular.x, mm->specular.y, mm->specular.z, mm->specular.w);
+        m.diffuse = make_float4(mm->diffuse.x, mm->diffuse.y, mm->diffuse.z, mm->diffuse.w);
+        m.emissive = make_float4(mm->emissive.x, mm->emissive.y, mm->emissive.z, mm->emissive.w);
     } else {
         const hpt_primitive *pr = p.prims + (-id - 2);
         const float4 *pp = reinterpret_cast<const float4 *>(pr);
