@@ -23,6 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ENGINE_CLOCK_HZ = 2.4e9         # MI355X peak engine clock (same guide)
+# vector-L1 ceiling for 16-B-per-lane gathers, measured with bench/micro/gather_exec.hip (node-shaped fetches
+# from an L2-resident table: 1.35; L1-resident: 1.45-1.58 lane-loads per clock per CU)
+L1_GATHER_CEILING = 1.45
 
 
 def algorithmic_bytes(costs, rays_primary, rays_bounce, n_pixels, spp):
@@ -152,16 +156,27 @@ def main():
             alg = algorithmic_bytes(costs, rays_p / world, rays_b / world, w * h / world, spp)
             achieved = alg / (kern_ms * 1e-3) / 1e9
             traffic = None
+            gather = None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc_path) and world == 1 and not args.spp:
-                traffic = json.load(open(pmc_path)).get(args.scene, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path)).get(args.scene, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
+                if pmc.get("tcp_lane_accesses_per_launch"):
+                    # what actually bounds the kernel: lane-loads served by the vector L1 per clock per CU
+                    n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+                    rate = pmc["tcp_lane_accesses_per_launch"] / (kern_ms * 1e-3) / n_cu / ENGINE_CLOCK_HZ
+                    gather = {"lane_loads_per_clk_per_cu": rate, "ceiling": L1_GATHER_CEILING, "frac": rate / L1_GATHER_CEILING,
+                              "lane_loads_per_ray": pmc["tcp_lane_accesses_per_launch"] / rays_frame,
+                              "source": "TCP_TOTAL_CACHE_ACCESSES of profiles/pmc_traffic.json over this run's kernel time"}
             roofline = {"bound": "hbm", "kernel": "render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
                         "bytes_per_primary_ray": 40.0 * costs["nodes_per_primary_ray"] + 48.0 * costs["tris_per_primary_ray"] + 144.0,
                         "bytes_per_bounce_ray": 40.0 * costs["nodes_per_bounce_ray"] + 48.0 * costs["tris_per_bounce_ray"] + 144.0,
+                        "l1_gather": gather,
                         "note": "BVH+triangles (%.0f MB) are cache-resident, so algorithmic bytes/s can exceed the HBM peak; "
-                                "see DESIGN.md §Roofline" % ((len(bvh["bbox"]) * 40 + len(bvh["triangles"]) * 48) / 1e6)}
+                                "the measured limiter is the vector-L1 gather rate (l1_gather); see DESIGN.md §Roofline"
+                                % ((len(bvh["bbox"]) * 40 + len(bvh["triangles"]) * 48) / 1e6)}
         out = {
             "metric": "Mrays/s (primary+bounce); ms_per_step = ms/frame %dx%d %dspp" % (w, h, spp),
             "value": rays_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",
