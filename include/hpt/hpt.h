@@ -82,6 +82,33 @@ int hpt_kernel_execute(hpt_ctx *ctx, hpt_pixel *image, int iteration);
  * Device pointers, n_pixels Pixels each. */
 int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_pixels, int iterations);
 
+/* The reference's live frame loop (what main.cpp runs) with its intended semantics; all
+ * per-pixel path state stays on the device between calls.
+ *
+ * hpt_first_bounce replaces OpenCL_Manager::initial_ray_kernel_execute (opencl_manager.hpp:33-37,
+ * opencl_manager.cpp:255-357; kernel initial_ray_kernel.cl:802-902): traces the camera ray (jitter cell 0)
+ * and the first shading event of every pixel of this shard, caches that state, and starts path 0 from it.
+ * Resets the per-pixel path counters.
+ *
+ * hpt_bounce replaces OpenCL_Manager::ray_kernel_execute (opencl_manager.hpp:39-48, opencl_manager.cpp:360-525;
+ * kernel ray_kernel.cl:817-929): advances every pixel's current path by ONE bounce (Russian roulette when
+ * bounce > rr_start, depth limit max_depth).  A path that ends leaves its colour as the pixel's contribution,
+ * the pixel's path counter goes up by one, and the pixel restarts from the cache with a fresh RNG key
+ * (seed, pixel, path number).  The committed kernel never restarts a finished pixel (ray_kernel.cl:899-921);
+ * that defect is not reproduced.  Returns HPT_ERR_INVALID when contributions of the previous hpt_bounce
+ * have not been folded yet (they would be lost), or before hpt_first_bounce.
+ *
+ * hpt_reconstruct_paths replaces OpenCL_Manager::reconstruct_kernel_execute as the live loop uses it
+ * (reconstruct_kernel.cl:10-37 without its gid < 1000 guard and G/B swap): for every pixel whose path ended in
+ * the last hpt_bounce, d_image = (1/n)*contribution + ((n-1)/n)*d_image with n = the pixel's path counter
+ * (n == 1: copy).  d_image: device pointer, width*height*3 floats.
+ *
+ * hpt_path_counts copies the per-pixel path counters (the reference's iteration_memory) to the host. */
+int hpt_first_bounce(hpt_ctx *ctx);
+int hpt_bounce(hpt_ctx *ctx);
+int hpt_reconstruct_paths(hpt_ctx *ctx, float *d_image);
+int hpt_path_counts(hpt_ctx *ctx, int32_t *counts);
+
 /* kernel_execute + the running mean of Pathtracer::render() in one call,
  * host image in/out (width*height*3 floats): what render() returns after
  * iteration `iteration` given the image after `iteration-1`. */

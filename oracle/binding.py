@@ -125,6 +125,28 @@ class OracleScene:
         lib().orc_render(C.byref(self.c), C.c_int(spp_begin), C.c_int(spp_end), C.c_int(px_begin), C.c_int(px_end), _p(image), C.byref(cnt), C.c_int(n_threads))
         return image, cnt.as_dict()
 
+    # ---- iterative pipeline (orc_iter_*): state is a numpy structured array mirroring orc_iter_pixel
+    ITER_PIXEL = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("weight", "<f4", 3), ("color", "<f4", 3),
+                           ("ctr", "<u4"), ("bounce", "<i4"),
+                           ("c_o", "<f4", 3), ("c_d", "<f4", 3), ("c_weight", "<f4", 3), ("c_color", "<f4", 3),
+                           ("c_ctr", "<u4"), ("c_finished", "<i4"), ("completed", "<i4"), ("fresh", "<i4"),
+                           ("contribution", "<f4", 3)])
+
+    class _IterState(C.Structure):
+        _fields_ = [("px", C.c_void_p), ("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64)]
+
+    def iter_first_bounce(self):
+        assert self.ITER_PIXEL.itemsize == 132
+        self.iter_px = np.zeros(self.npx, self.ITER_PIXEL)
+        self.iter_st = self._IterState(self.iter_px.ctypes.data, 0, 0)
+        lib().orc_iter_first_bounce(C.byref(self.c), C.byref(self.iter_st))
+
+    def iter_bounce(self):
+        lib().orc_iter_bounce(C.byref(self.c), C.byref(self.iter_st))
+
+    def iter_reconstruct(self, image):
+        lib().orc_iter_reconstruct(C.byref(self.c), C.byref(self.iter_st), _p(image))
+
     def camera_ray(self, gid, iteration):
         o = np.empty(3, np.float32); d = np.empty(3, np.float32)
         lib().orc_camera_ray(C.byref(self.c), C.c_int(gid), C.c_int(iteration), _p(o), _p(d))

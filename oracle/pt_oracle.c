@@ -313,6 +313,60 @@ static v3 refractive_dir(v3 N, v3 d, const hpt_material *m) {
     return add(scale(N, ndoti + ndoti), d);
 }
 
+/* ---- one bounce of the loop body pathtracer_kernel.cl:759-849 after the closest hit (id, t) of ray (o, d):
+ * returns 1 when the path goes on with the new ray left in (o, d), 0 when it ended (light, miss, roulette) ---- */
+static int shade_bounce(const orc_scene *s, int id, float t, v3 *o, v3 *d, uint32_t key, uint32_t *ctr, int b,
+                        v3 *color, v3 *weight) {
+    v3 no, nd;
+    if (id != HPT_HIT_MISS) {
+        hpt_material m;
+        v3 point = add(*o, scale(*d, t));          /* point_at, ray_kernel.cl:82-85 */
+        v3 normal;
+        if (id >= 0) {
+            const hpt_triangle *tri = &s->triangles[id];
+            m = s->materials[0];
+            normal = normalize(cross(V4(tri->e1), V4(tri->e2)));
+            if (dot(normal, *d) > 0.0f) normal = neg(normal);
+        } else {
+            const hpt_primitive *p = &s->primitives[-id - 2];
+            m.refractive = p->refractive; m.specular = p->specular;
+            m.diffuse = p->diffuse; m.emissive = p->emissive;
+            if (p->type.x == 0) normal = normalize(sub(point, V4(p->center)));
+            else normal = normalize(V4(p->plane_normal));
+        }
+        if (islight(&m)) {
+            *color = add(*color, mul(*weight, V4(m.emissive)));
+            return 0;
+        }
+        int fresnel = draw(key, ctr) < schlick_fresnel(normal, *d, &m);
+        if (fresnel && isspecular(&m)) {
+            nd = reflect_dir(normal, *d);
+            no = add(point, scale(nd, EPSILON));
+        } else if (isrefractive(&m)) {
+            if (fresnel) nd = reflect_dir(normal, *d);
+            else nd = refractive_dir(normal, *d, &m);
+            no = add(point, scale(nd, EPSILON));
+        } else {
+            *weight = mul(*weight, V4(m.diffuse));
+            nd = random_sample_hemisphere(normal, key, ctr);
+            no = add(point, scale(nd, EPSILON));
+            *weight = scale(*weight, dot(normal, nd) * s->cfg.diffuse_scale);
+        }
+    } else {
+        *color = add(*color, mul(*weight, V(BACKGROUND[0], BACKGROUND[1], BACKGROUND[2])));
+        return 0;
+    }
+    if (b > s->cfg.rr_start) {                    /* pathtracer_kernel.cl:836-845 */
+        float m = (weight->x > weight->y) ? weight->x : weight->y;
+        m = (weight->z > m) ? weight->z : m;
+        float pterm = draw(key, ctr);
+        if (m < pterm) return 0;
+        *weight = V(weight->x / m, weight->y / m, weight->z / m);
+    }
+    *o = no; *d = nd;
+    return 1;
+}
+
 /* ---- one radiance sample: pathtracer_kernel.cl:748-852 (loop form) ---- */
 static void path_sample(const orc_scene *s, int gid, int iteration, float rgb[3], orc_counters *c) {
     uint32_t key = path_key(s->cfg.seed, (uint32_t)gid, (uint32_t)iteration), ctr = 0;
@@ -326,55 +380,85 @@ static void path_sample(const orc_scene *s, int gid, int iteration, float rgb[3]
         int id = closest_hit(s, o, d, &t, &nn, &nt);
         if (b == 0) { c->rays_primary++; c->nodes_primary += nn; c->tris_primary += nt; }
         else        { c->rays_bounce++;  c->nodes_bounce += nn;  c->tris_bounce += nt; }
-        v3 no, nd;
-        if (id != HPT_HIT_MISS) {
-            hpt_material m;
-            v3 point = add(o, scale(d, t));          /* point_at, ray_kernel.cl:82-85 */
-            v3 normal;
-            if (id >= 0) {
-                const hpt_triangle *tri = &s->triangles[id];
-                m = s->materials[0];
-                normal = normalize(cross(V4(tri->e1), V4(tri->e2)));
-                if (dot(normal, d) > 0.0f) normal = neg(normal);
-            } else {
-                const hpt_primitive *p = &s->primitives[-id - 2];
-                m.refractive = p->refractive; m.specular = p->specular;
-                m.diffuse = p->diffuse; m.emissive = p->emissive;
-                if (p->type.x == 0) normal = normalize(sub(point, V4(p->center)));
-                else normal = normalize(V4(p->plane_normal));
-            }
-            if (islight(&m)) {
-                color = add(color, mul(weight, V4(m.emissive)));
-                break;
-            }
-            int fresnel = draw(key, &ctr) < schlick_fresnel(normal, d, &m);
-            if (fresnel && isspecular(&m)) {
-                nd = reflect_dir(normal, d);
-                no = add(point, scale(nd, EPSILON));
-            } else if (isrefractive(&m)) {
-                if (fresnel) nd = reflect_dir(normal, d);
-                else nd = refractive_dir(normal, d, &m);
-                no = add(point, scale(nd, EPSILON));
-            } else {
-                weight = mul(weight, V4(m.diffuse));
-                nd = random_sample_hemisphere(normal, key, &ctr);
-                no = add(point, scale(nd, EPSILON));
-                weight = scale(weight, dot(normal, nd) * s->cfg.diffuse_scale);
-            }
-        } else {
-            color = add(color, mul(weight, V(BACKGROUND[0], BACKGROUND[1], BACKGROUND[2])));
-            break;
-        }
-        if (b > s->cfg.rr_start) {                    /* pathtracer_kernel.cl:836-845 */
-            float m = (weight.x > weight.y) ? weight.x : weight.y;
-            m = (weight.z > m) ? weight.z : m;
-            float pterm = draw(key, &ctr);
-            if (m < pterm) break;
-            weight = V(weight.x / m, weight.y / m, weight.z / m);
-        }
-        o = no; d = nd;
+        if (!shade_bounce(s, id, t, &o, &d, key, &ctr, b, &color, &weight)) break;
     }
     rgb[0] = color.x; rgb[1] = color.y; rgb[2] = color.z;
+}
+
+/* ---- the iterative pipeline with its INTENDED semantics (initial_ray_kernel.cl:802-902,
+ * ray_kernel.cl:817-929, reconstruct_kernel.cl:10-37): cache bounce 0 of every pixel; each call advances every
+ * pixel's current path by one bounce; a path that ends leaves its colour as the pixel's contribution, counts as
+ * completed, and the pixel restarts from the cache; reconstruct folds fresh contributions into the per-pixel
+ * running mean.  Path n of a pixel draws from key(seed, pixel, n), counter continuing after the cached bounce. ---- */
+void orc_iter_first_bounce(const orc_scene *s, orc_iter_state *st) {
+    const int npx = s->width * s->height;
+    for (int gid = 0; gid < npx; gid++) {
+        orc_iter_pixel *q = &st->px[gid];
+        uint32_t key = path_key(s->cfg.seed, (uint32_t)gid, 0u), ctr = 0;
+        v3 o, d;
+        camera_ray(s, gid, 0, key, &ctr, &o, &d);
+        v3 color = V(0, 0, 0), weight = V(1, 1, 1);
+        float t;
+        uint64_t nn = 0, nt = 0;
+        int id = closest_hit(s, o, d, &t, &nn, &nt);
+        st->rays_primary++;
+        int go_on = shade_bounce(s, id, t, &o, &d, key, &ctr, 0, &color, &weight);
+        q->c_finished = (!go_on || 1 >= s->cfg.max_depth);
+        q->c_o[0] = o.x; q->c_o[1] = o.y; q->c_o[2] = o.z; q->c_d[0] = d.x; q->c_d[1] = d.y; q->c_d[2] = d.z;
+        q->c_weight[0] = weight.x; q->c_weight[1] = weight.y; q->c_weight[2] = weight.z;
+        q->c_color[0] = color.x; q->c_color[1] = color.y; q->c_color[2] = color.z;
+        q->c_ctr = ctr;
+        memcpy(q->o, q->c_o, sizeof q->o); memcpy(q->d, q->c_d, sizeof q->d);
+        memcpy(q->weight, q->c_weight, sizeof q->weight); memcpy(q->color, q->c_color, sizeof q->color);
+        q->ctr = ctr; q->bounce = 1; q->completed = 0; q->fresh = 0;
+        q->contribution[0] = q->contribution[1] = q->contribution[2] = 0.0f;
+    }
+}
+
+void orc_iter_bounce(const orc_scene *s, orc_iter_state *st) {
+    const int npx = s->width * s->height;
+    for (int gid = 0; gid < npx; gid++) {
+        orc_iter_pixel *q = &st->px[gid];
+        int ended;
+        v3 color = V(q->color[0], q->color[1], q->color[2]);
+        if (q->c_finished) ended = 1;              /* the cached bounce already ended the path: one path per call */
+        else {
+            uint32_t key = path_key(s->cfg.seed, (uint32_t)gid, (uint32_t)q->completed), ctr = q->ctr;
+            v3 o = V(q->o[0], q->o[1], q->o[2]), d = V(q->d[0], q->d[1], q->d[2]);
+            v3 weight = V(q->weight[0], q->weight[1], q->weight[2]);
+            float t;
+            uint64_t nn = 0, nt = 0;
+            int id = closest_hit(s, o, d, &t, &nn, &nt);
+            st->rays_bounce++;
+            int go_on = shade_bounce(s, id, t, &o, &d, key, &ctr, q->bounce, &color, &weight);
+            q->bounce++;
+            ended = (!go_on || q->bounce >= s->cfg.max_depth);
+            if (!ended) {
+                q->o[0] = o.x; q->o[1] = o.y; q->o[2] = o.z; q->d[0] = d.x; q->d[1] = d.y; q->d[2] = d.z;
+                q->weight[0] = weight.x; q->weight[1] = weight.y; q->weight[2] = weight.z;
+                q->color[0] = color.x; q->color[1] = color.y; q->color[2] = color.z;
+                q->ctr = ctr;
+            }
+        }
+        if (ended) {
+            q->contribution[0] = color.x; q->contribution[1] = color.y; q->contribution[2] = color.z;
+            q->completed++;
+            q->fresh = 1;
+            memcpy(q->o, q->c_o, sizeof q->o); memcpy(q->d, q->c_d, sizeof q->d);
+            memcpy(q->weight, q->c_weight, sizeof q->weight); memcpy(q->color, q->c_color, sizeof q->color);
+            q->ctr = q->c_ctr; q->bounce = 1;
+        }
+    }
+}
+
+void orc_iter_reconstruct(const orc_scene *s, orc_iter_state *st, float *image) {
+    const int npx = s->width * s->height;
+    for (int gid = 0; gid < npx; gid++) {
+        orc_iter_pixel *q = &st->px[gid];
+        if (!q->fresh) continue;
+        orc_accumulate(image + 3 * (int64_t)gid, q->contribution, 3, q->completed);
+        q->fresh = 0;
+    }
 }
 
 static void counters_add(orc_counters *a, const orc_counters *b) {

@@ -44,6 +44,21 @@ void orc_accumulate(float *image, const float *sample, int64_t n_floats, int ite
 /* spp loop: image = running mean over iterations [spp_begin, spp_end) */
 void orc_render(const orc_scene *s, int spp_begin, int spp_end, int px_begin, int px_end,
                 float *image, orc_counters *c, int n_threads);
+/* The iterative pipeline with its intended semantics (initial_ray_kernel.cl:802-902,
+ * ray_kernel.cl:817-929, reconstruct_kernel.cl:10-37); see the comment above orc_iter_first_bounce. */
+typedef struct {
+    float o[3], d[3], weight[3], color[3];          /* current path of the pixel */
+    uint32_t ctr; int32_t bounce;
+    float c_o[3], c_d[3], c_weight[3], c_color[3];  /* cache: state after bounce 0 */
+    uint32_t c_ctr; int32_t c_finished;
+    int32_t completed, fresh;                       /* paths folded so far; contribution waits for reconstruct */
+    float contribution[3];
+} orc_iter_pixel;
+typedef struct { orc_iter_pixel *px; uint64_t rays_primary, rays_bounce; } orc_iter_state;
+void orc_iter_first_bounce(const orc_scene *s, orc_iter_state *st);
+void orc_iter_bounce(const orc_scene *s, orc_iter_state *st);
+void orc_iter_reconstruct(const orc_scene *s, orc_iter_state *st, float *image);
+
 /* png_writer.cpp:7-17 */
 void orc_tonemap(const float *image, uint8_t *rgb8, int64_t n_floats);
 

@@ -22,6 +22,7 @@ C_ABI_SYMBOLS = [
     "hpt_upload_bvh", "hpt_set_scene", "hpt_set_camera", "hpt_set_config", "hpt_get_config", "hpt_kernel_execute",
     "hpt_reconstruct", "hpt_render_sample", "hpt_render", "hpt_primary_hits", "hpt_slab_floats", "hpt_pack_tiles",
     "hpt_unpack_tiles", "hpt_tonemap", "hpt_synchronize", "hpt_get_stats",
+    "hpt_first_bounce", "hpt_bounce", "hpt_reconstruct_paths", "hpt_path_counts",
 ]
 
 
@@ -200,6 +201,21 @@ class Backend:
 
     def reconstruct(self, d_image, d_sample, n_pixels, iterations):
         self._chk(self.L.hpt_reconstruct(self.h, C.c_void_p(d_image), C.c_void_p(d_sample), n_pixels, iterations))
+
+    # iterative pipeline (initial_ray_kernel / ray_kernel / reconstruct_kernel of the live frame loop)
+    def first_bounce(self):
+        self._chk(self.L.hpt_first_bounce(self.h))
+
+    def bounce(self):
+        self._chk(self.L.hpt_bounce(self.h))
+
+    def reconstruct_paths(self, d_image):
+        self._chk(self.L.hpt_reconstruct_paths(self.h, C.c_void_p(d_image)))
+
+    def path_counts(self):
+        counts = np.empty(self.width * self.height, np.int32)
+        self._chk(self.L.hpt_path_counts(self.h, _p(counts)))
+        return counts
 
     def primary_hits(self, iteration):
         n = self.width * self.height

@@ -115,33 +115,28 @@ Pixel *Pathtracer::render(int n) {
     return image_data.data();
 }
 
-void Pathtracer::iterative_render_first_bounce() {
-    // The reference caches bounce 0 here so later samples can restart from it
-    // (initial_ray_kernel.cl); every sample of this backend regenerates its jittered
-    // camera ray on the device, which costs less than reading a cache back from HBM.
-}
-
-void Pathtracer::iterative_render() {
+// The live frame loop of main.cpp:121-151 with the semantics the reference intends, on
+// device-resident state: hpt_first_bounce caches bounce 0, every iterative_render() advances each pixel's
+// path by one bounce, reconstruct() folds the paths that ended into the per-pixel running mean.
+void Pathtracer::iterative_render_first_bounce() {       // reference pathtracer.cpp:117-157
     if (!ctx) return;
-    if (hpt_kernel_execute(ctx, sample_data.data(), iterations) != HPT_OK) return;
-    pending_iteration = iterations;
-    iterations++;
+    size_t bytes = image_data.size() * sizeof(Pixel);
+    if (!d_image && hipMalloc((void **)&d_image, bytes) != hipSuccess) return;
+    if (hipMemset(d_image, 0, bytes) != hipSuccess) return;
+    for (Pixel &px : image_data) px.red = px.green = px.blue = 0.0f;
+    (void)hpt_first_bounce(ctx);
 }
 
-void Pathtracer::reconstruct() {
-    if (!ctx || pending_iteration < 0) return;
-    // running mean of pathtracer.cpp:200-217 on the host copy (w*h*3 floats; the device form is hpt_reconstruct)
-    int it = pending_iteration + 1;
-    float *img = &image_data[0].red;
-    const float *smp = &sample_data[0].red;
-    size_t n = image_data.size() * 3;
-    if (it > 1) {
-        float i1 = 1 / (float)it, i2 = (float)(it - 1) / (float)it;
-        for (size_t i = 0; i < n; i++) img[i] = (i1 * smp[i]) + (i2 * img[i]);
-    } else {
-        for (size_t i = 0; i < n; i++) img[i] = smp[i];
-    }
-    pending_iteration = -1;
+void Pathtracer::iterative_render() {                    // reference pathtracer.cpp:159-176
+    if (!ctx) return;
+    (void)hpt_bounce(ctx);
+}
+
+void Pathtracer::reconstruct() {                         // reference pathtracer.cpp:178-182
+    if (!ctx || !d_image) return;
+    if (hpt_reconstruct_paths(ctx, d_image) != HPT_OK) return;
+    if (hpt_synchronize(ctx) != HPT_OK) return;
+    (void)hipMemcpy(image_data.data(), d_image, image_data.size() * sizeof(Pixel), hipMemcpyDeviceToHost);
 }
 
 }  // namespace hpt

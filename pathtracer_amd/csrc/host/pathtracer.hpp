@@ -35,8 +35,10 @@ public:
     Pixel *render(int n);
 
     // Progressive interface of the live GLUT loop (main.cpp:112, 130-131), with the
-    // semantics the reference intends: each iterative_render()
-    // produces one finished radiance sample per pixel, reconstruct() folds it in.
+    // semantics the reference intends: the first call caches bounce 0
+    // of every pixel, each iterative_render() advances every pixel's path by one bounce
+    // (a path that ends restarts from the cache), reconstruct() folds the paths that
+    // ended into the per-pixel running mean and refreshes get_image().
     void iterative_render_first_bounce();
     void iterative_render();
     void reconstruct();
@@ -50,7 +52,6 @@ public:
 private:
     hpt_ctx *ctx = nullptr;
     int width, height, iterations = 0;
-    int pending_iteration = -1;              // sample produced by iterative_render(), not yet reconstructed
     std::vector<Pixel> image_data, sample_data;
     std::vector<hpt_triangle> triangles;
     BoundingVolumeHierarchy bvh_constructor;

@@ -78,6 +78,10 @@ struct hpt_ctx {
     size_t samples_bytes = 0;
     size_t sample_budget_bytes = (size_t)8 << 30;   // HPT_SAMPLE_BUDGET_MB overrides; bounds iterations per launch
     int blocks_per_cu_cap = 0;       // 0 = occupancy limit (HPT_BLOCKS_PER_CU overrides)
+    void *d_iter = nullptr;          // per-pixel state of the iterative pipeline (one allocation), made by hpt_first_bounce
+    IterState iter{};
+    int iter_ready = 0;              // 1 after hpt_first_bounce
+    int iter_pending = 0;            // 1 between hpt_bounce and hpt_reconstruct_paths
     std::string err;
 };
 
@@ -285,6 +289,7 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);
+    (void)hipFree(ctx->d_iter);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -451,6 +456,84 @@ int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_p
     if (n == 0) return HPT_OK;
     hipLaunchKernelGGL(reconstruct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, d_sample, n, iterations);
     HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+// ---- iterative pipeline -------------------------------------------------------------------------------
+static int iter_launch_params(hpt_ctx *ctx, RenderParams &p, unsigned &blocks, size_t &lds) {
+    int rc = fill_params(ctx, p, nullptr, 0, 1, 0);
+    if (rc) return rc;
+    if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
+        return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
+    blocks = (p.n_slots + kBlock - 1) / kBlock;
+    lds = stack_lds_bytes(ctx, kBlock);
+    return HPT_OK;
+}
+
+int hpt_first_bounce(hpt_ctx *ctx) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    RenderParams p; unsigned blocks; size_t lds;
+    if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
+    const size_t npx = (size_t)ctx->width * ctx->height;
+    if (!ctx->d_iter) {
+        HIP_TRY(ctx, hipMalloc(&ctx->d_iter, npx * (6 * 16 + 2 * 8 + 4 + 16)));
+        char *q = (char *)ctx->d_iter;                       // 16-B members first: every array stays aligned
+        ctx->iter.cur_a = (float4 *)q; q += npx * 16; ctx->iter.cur_b = (float4 *)q; q += npx * 16;
+        ctx->iter.cur_c = (float4 *)q; q += npx * 16; ctx->iter.c_a = (float4 *)q; q += npx * 16;
+        ctx->iter.c_b = (float4 *)q; q += npx * 16; ctx->iter.c_c = (float4 *)q; q += npx * 16;
+        ctx->iter.contrib = (float4 *)q; q += npx * 16;
+        ctx->iter.cur_d = (uint2 *)q; q += npx * 8; ctx->iter.c_d = (uint2 *)q; q += npx * 8;
+        ctx->iter.completed = (int32_t *)q;
+    }
+    // pixels outside the shard keep zeroed state (count 0, no contribution)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_iter, 0, npx * (6 * 16 + 2 * 8 + 4 + 16), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    ctx->timed = false;
+    ctx->iter_ready = 1; ctx->iter_pending = 0;
+    if (blocks == 0) return HPT_OK;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)iter_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(iter_first_kernel, dim3(blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_bounce(hpt_ctx *ctx) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!ctx->iter_ready) return fail(ctx, HPT_ERR_INVALID, "hpt_bounce before hpt_first_bounce");
+    if (ctx->iter_pending) return fail(ctx, HPT_ERR_INVALID, "contributions of the previous hpt_bounce are not folded yet: call hpt_reconstruct_paths");
+    RenderParams p; unsigned blocks; size_t lds;
+    if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
+    ctx->iter_pending = 1;
+    if (blocks == 0) return HPT_OK;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)iter_bounce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(iter_bounce_kernel, dim3(blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_reconstruct_paths(hpt_ctx *ctx, float *d_image) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image) return fail(ctx, HPT_ERR_INVALID, "bad reconstruct_paths arguments");
+    if (!ctx->iter_ready) return fail(ctx, HPT_ERR_INVALID, "hpt_reconstruct_paths before hpt_first_bounce");
+    RenderParams p; unsigned blocks; size_t lds;
+    if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
+    ctx->iter_pending = 0;
+    if (blocks == 0) return HPT_OK;
+    hipLaunchKernelGGL(iter_reconstruct_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter, d_image);
+    HIP_TRY(ctx, hipGetLastError());
+    return HPT_OK;
+}
+
+int hpt_path_counts(hpt_ctx *ctx, int32_t *counts) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!counts) return fail(ctx, HPT_ERR_INVALID, "bad path_counts arguments");
+    if (!ctx->iter_ready) return fail(ctx, HPT_ERR_INVALID, "hpt_path_counts before hpt_first_bounce");
+    HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->iter.completed, (size_t)ctx->width * ctx->height * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return HPT_OK;
 }
 

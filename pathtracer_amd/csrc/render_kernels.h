@@ -702,6 +702,113 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const RenderParams p,
     p.hit_t[gid] = t;
 }
 
+// ======================= iterative pipeline (hpt_first_bounce / hpt_bounce / hpt_reconstruct_paths) ==========
+// The reference's live frame loop (initial_ray_kernel.cl:802-902, ray_kernel.cl:817-929,
+// reconstruct_kernel.cl:10-37) with its INTENDED semantics (the committed state machine never
+// restarts a finished pixel and is not reproduced): bounce 0 of every pixel is traced once and cached; each
+// hpt_bounce advances every pixel's current path by one bounce; a path that ends leaves its colour as the
+// pixel's contribution, counts as completed, and the pixel restarts from the cache; reconstruct folds fresh
+// contributions into the per-pixel running mean.  Path n of a pixel draws from key(seed, pixel, n), counter
+// continuing after the cached bounce.  All per-pixel state stays in HBM (the reference moves it over PCIe
+// both ways on every call).  One thread per pixel slot of the shard, one ray per thread per launch.
+struct IterState {
+    float4 *cur_a, *cur_b, *cur_c;   // current path: {o.xyz, weight.x} {d.xyz, weight.y} {color.xyz, weight.z}
+    uint2 *cur_d;                    // {rng counter, bounces done}
+    float4 *c_a, *c_b, *c_c;         // cache (state after bounce 0), same packing
+    uint2 *c_d;                      // {rng counter, 1 if bounce 0 ended the path}
+    int32_t *completed;              // paths folded per pixel (the reference's iteration_memory)
+    float4 *contrib;                 // {rgb of the last finished path, 1 if it waits for reconstruct}
+};
+
+__device__ __forceinline__ void iter_count_rays(const RenderParams &p, int counter, bool traced) {
+    __shared__ unsigned block_rays;
+    if (threadIdx.x == 0) block_rays = 0;
+    __syncthreads();
+    const unsigned long long m = hpt_ballot(traced);
+    if ((threadIdx.x & 63u) == 0u && m) atomicAdd(&block_rays, (unsigned)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && block_rays) atomicAdd(p.counters + counter, (unsigned long long)block_rays);
+}
+
+__global__ void __launch_bounds__(256) iter_first_kernel(const RenderParams p, const IterState it) {
+    uint2 *stack = hpt_lds_stack + threadIdx.x;
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = slot < p.n_slots ? work_to_pixel(p, slot) : -1;
+    if (gid >= 0) {
+        const uint32_t key = path_key(p.seed, (uint32_t)gid, 0u);
+        uint32_t ctr = 0;
+        Ray r = camera_ray(p, gid, 0, key, ctr);
+        f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+        float t;
+        const int id = closest_hit(p, r.o, r.d, t, stack, blockDim.x);
+        const bool go_on = shade_bounce(p, id, t, r, key, ctr, 0, color, weight);
+        const bool finished = !go_on || 1 >= p.max_depth;
+        const float4 a = make_float4(r.o.x, r.o.y, r.o.z, weight.x), b = make_float4(r.d.x, r.d.y, r.d.z, weight.y);
+        const float4 c = make_float4(color.x, color.y, color.z, weight.z);
+        it.c_a[gid] = a; it.c_b[gid] = b; it.c_c[gid] = c; it.c_d[gid] = make_uint2(ctr, finished ? 1u : 0u);
+        it.cur_a[gid] = a; it.cur_b[gid] = b; it.cur_c[gid] = c; it.cur_d[gid] = make_uint2(ctr, 1u);
+        it.completed[gid] = 0;
+        it.contrib[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    iter_count_rays(p, 0, gid >= 0);
+}
+
+__global__ void __launch_bounds__(256) iter_bounce_kernel(const RenderParams p, const IterState it) {
+    uint2 *stack = hpt_lds_stack + threadIdx.x;
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = slot < p.n_slots ? work_to_pixel(p, slot) : -1;
+    bool traced = false;
+    if (gid >= 0) {
+        const uint2 cd = it.c_d[gid];
+        float4 c = it.cur_c[gid];
+        f3 color = mk3(c.x, c.y, c.z);
+        bool ended = cd.y != 0u;                 // the cached bounce already ended the path: one path per call
+        if (!ended) {
+            const float4 a = it.cur_a[gid], b = it.cur_b[gid];
+            const uint2 d = it.cur_d[gid];
+            const int n = it.completed[gid];
+            const uint32_t key = path_key(p.seed, (uint32_t)gid, (uint32_t)n);
+            uint32_t ctr = d.x;
+            int bounce = (int)d.y;
+            Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(b.x, b.y, b.z);
+            f3 weight = mk3(a.w, b.w, c.w);
+            float t;
+            const int id = closest_hit(p, r.o, r.d, t, stack, blockDim.x);
+            traced = true;
+            const bool go_on = shade_bounce(p, id, t, r, key, ctr, bounce, color, weight);
+            bounce++;
+            ended = !go_on || bounce >= p.max_depth;
+            if (!ended) {
+                it.cur_a[gid] = make_float4(r.o.x, r.o.y, r.o.z, weight.x);
+                it.cur_b[gid] = make_float4(r.d.x, r.d.y, r.d.z, weight.y);
+                it.cur_c[gid] = make_float4(color.x, color.y, color.z, weight.z);
+                it.cur_d[gid] = make_uint2(ctr, (unsigned)bounce);
+            }
+        }
+        if (ended) {
+            it.contrib[gid] = make_float4(color.x, color.y, color.z, 1.0f);
+            it.completed[gid] = it.completed[gid] + 1;
+            it.cur_a[gid] = it.c_a[gid]; it.cur_b[gid] = it.c_b[gid]; it.cur_c[gid] = it.c_c[gid];
+            it.cur_d[gid] = make_uint2(cd.x, 1u);
+        }
+    }
+    iter_count_rays(p, 1, traced);
+}
+
+// image = (1/n)*contribution + ((n-1)/n)*image with n = the pixel's completed paths (pathtracer.cpp:200-217
+// per pixel, as reconstruct_kernel.cl:25-36 intends), for pixels whose path ended in the last hpt_bounce.
+__global__ void __launch_bounds__(256) iter_reconstruct_kernel(const RenderParams p, const IterState it, float *__restrict__ image) {
+    const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = slot < p.n_slots ? work_to_pixel(p, slot) : -1;
+    if (gid < 0) return;
+    const float4 c = it.contrib[gid];
+    if (c.w == 0.0f) return;
+    float *px = image + 3 * (size_t)gid;
+    const f3 mean = fold_sample(mk3(px[0], px[1], px[2]), mk3(c.x, c.y, c.z), it.completed[gid], false);
+    px[0] = mean.x; px[1] = mean.y; px[2] = mean.z;
+    it.contrib[gid] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
 // running mean of Pathtracer::render(), pathtracer.cpp:200-217 (the committed
 // reconstruct_kernel.cl swaps G/B and stops at gid 1000: not reproduced)
 __global__ void reconstruct_kernel(float *__restrict__ image, const float *__restrict__ sample, long n_floats, int iterations) {

@@ -252,10 +252,84 @@ def test_pathtracer_facade_matches_oracle():
     assert mismatch(img, o.render(3, 5, image=oimg.copy())[0]) == 0
     pt2 = api.Pathtracer(64, 64)
     pt2.set_triangles(s["verts"].reshape(-1, 3)); pt2.set_scene(s["primitives"], s["materials"]); pt2.set_camera(); pt2.set_config(s["cfg"])
+    # live-loop interface: first bounce cached, one bounce per call, finished paths folded per pixel
+    o.iter_first_bounce()
+    want = np.zeros((64 * 64, 3), np.float32)
     pt2.iterative_render_first_bounce()
-    for _ in range(3):
+    for _ in range(6):
         pt2.iterative_render(); pt2.reconstruct()
-    assert mismatch(pt2.get_image(), oimg) == 0
+        o.iter_bounce(); o.iter_reconstruct(want)
+    assert mismatch(pt2.get_image(), want) == 0
+
+
+@pytest.mark.parametrize("name,kw,cfg", [
+    ("cornell", dict(width=64, height=64), None),
+    ("random", dict(n=2000, seed=1, width=64, height=64), dict(max_depth=15, rr_start=3, diffuse_scale=1.0, seed=7)),
+    ("glossy", dict(width=48, height=27), dict(max_depth=6, rr_start=1, diffuse_scale=1.0, seed=99)),
+    ("cornell", dict(width=40, height=24), dict(max_depth=1, rr_start=3, diffuse_scale=2.0, seed=5)),
+])
+def test_iterative_pipeline_matches_oracle(name, kw, cfg):
+    """hpt_first_bounce / hpt_bounce / hpt_reconstruct_paths against the oracle's restatement of the live
+    frame loop with its intended semantics: after every call the running-mean image, the per-pixel path
+    counters and the ray counters are bit-identical.  max_depth = 1: the cached bounce ends every path, so
+    each call completes one path per pixel."""
+    from oracle import binding as orc
+    s, bvh, o = get_scene(name, **kw)
+    if cfg is not None:
+        s = dict(s, cfg=cfg)
+        o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], s["primitives"], s["materials"], s["camera"],
+                            s["width"], s["height"], cfg)
+    be = backend_for(s, bvh)
+    d = dev_image(be)
+    want = np.zeros((s["width"] * s["height"], 3), np.float32)
+    with pytest.raises(api.HptError):
+        be.bounce()                                       # before first_bounce
+    be.first_bounce(); o.iter_first_bounce()
+    for k in range(12):
+        be.bounce(); o.iter_bounce()
+        if k == 3:
+            with pytest.raises(api.HptError):
+                be.bounce()                               # contributions not folded yet
+        be.reconstruct_paths(d.data_ptr()); o.iter_reconstruct(want)
+        be.synchronize()
+        assert mismatch(d.cpu().numpy(), want) == 0, k
+        assert np.array_equal(be.path_counts(), o.iter_px["completed"]), k
+    st = be.stats()
+    assert st["rays_primary"] == o.iter_st.rays_primary and st["rays_bounce"] == o.iter_st.rays_bounce
+    assert o.iter_px["completed"].max() >= 2              # some pixels restarted from the cache
+    # restarting: same sequence again
+    be.first_bounce(); o.iter_first_bounce()
+    d.zero_(); want[:] = 0
+    for k in range(3):
+        be.bounce(); be.reconstruct_paths(d.data_ptr()); o.iter_bounce(); o.iter_reconstruct(want)
+    be.synchronize()
+    assert mismatch(d.cpu().numpy(), want) == 0
+
+
+def test_iterative_pipeline_on_a_shard():
+    """With a shard set the iterative calls touch this rank's tiles only; the union over ranks is the
+    unsharded result."""
+    s, bvh, o = get_scene("cornell", width=64, height=48)
+    full = backend_for(s, bvh)
+    a = dev_image(full)
+    full.first_bounce()
+    for _ in range(5):
+        full.bounce(); full.reconstruct_paths(a.data_ptr())
+    full.synchronize()
+    acc = torch.zeros_like(a)
+    counts = np.zeros(64 * 48, np.int32)
+    for r in range(3):
+        be = backend_for(s, bvh)
+        be.set_shard(r, 3)
+        d = dev_image(be)
+        be.first_bounce()
+        for _ in range(5):
+            be.bounce(); be.reconstruct_paths(d.data_ptr())
+        be.synchronize()
+        acc += d                                          # shards are disjoint, the rest stays 0
+        counts += be.path_counts()
+    assert torch.equal(acc.view(torch.int32), a.view(torch.int32))
+    assert np.array_equal(counts, full.path_counts())
 
 
 def test_full_size_properties_c3():
