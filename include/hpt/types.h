@@ -79,7 +79,7 @@ _Static_assert(sizeof(hpt_camera) == 64, "Camera");
 /* Render constants that are compile-time literals in the reference
  * (SURVEY.md §5 "Config / flags"); defaults reproduce them. */
 typedef struct {
-    int32_t  max_depth;      /* MAXDEPTH, pathtracer_kernel.cl:11 (15) */
+    int32_t  max_depth;      /* MAXDEPTH, pathtracer_kernel.cl:11 (15); >= 1 */
     int32_t  rr_start;       /* RR applies when bounce index b > rr_start, pathtracer_kernel.cl:836 (3) */
     float    diffuse_scale;  /* factor on dot(n,dir) for a diffuse bounce: 2.0 in pathtracer_kernel.cl:822,
                                 1.0 in ray_kernel.cl:785-786 */

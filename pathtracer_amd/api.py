@@ -27,7 +27,12 @@ C_ABI_SYMBOLS = [
 
 
 class HptError(RuntimeError):
-    pass
+    """A C-ABI call returned a negative hpt_status; `.status` holds it (-1 invalid, -2 device, -3 out of
+    device memory, -4 BVH), the message is hpt_last_error()."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
 
 
 def lib():
@@ -129,7 +134,7 @@ class Backend:
         h = C.c_void_p()
         rc = self.L.hpt_create(width, height, device, C.byref(h))
         if rc != 0:
-            raise HptError("hpt_create: %s" % self.L.hpt_last_error(None).decode())
+            raise HptError("hpt_create: %s" % self.L.hpt_last_error(None).decode(), rc)
         self.h = h
         self.width, self.height = width, height
 
@@ -146,7 +151,7 @@ class Backend:
 
     def _chk(self, rc):
         if rc != 0:
-            raise HptError("hpt error %d: %s" % (rc, self.L.hpt_last_error(self.h).decode()))
+            raise HptError("hpt error %d: %s" % (rc, self.L.hpt_last_error(self.h).decode()), rc)
 
     def set_stream(self, stream_handle):
         self._chk(self.L.hpt_set_stream(self.h, C.c_void_p(stream_handle)))

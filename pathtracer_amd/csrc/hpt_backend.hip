@@ -103,6 +103,17 @@ int fail(hpt_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, HPT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// device allocation: out of memory is its own status (HPT_ERR_NOMEM), anything else a device error
+#define HIP_ALLOC(ctx, pptr, bytes)                                                                     \
+    do {                                                                                              \
+        hipError_t e_ = hipMalloc((void **)(pptr), (bytes));                                          \
+        if (e_ == hipErrorOutOfMemory) {                                                              \
+            (void)hipGetLastError();                                                                  \
+            return fail(ctx, HPT_ERR_NOMEM, "out of device memory allocating %zu bytes", (size_t)(bytes)); \
+        }                                                                                             \
+        if (e_ != hipSuccess) return fail(ctx, HPT_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e_)); \
+    } while (0)
+
 int bind(hpt_ctx *ctx) {
     if (!ctx) return HPT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -113,7 +124,7 @@ template <class T>
 int replace_buffer(hpt_ctx *ctx, T *&dptr, const void *host, size_t bytes) {
     if (dptr) { HIP_TRY(ctx, hipFree(dptr)); dptr = nullptr; }
     if (bytes == 0) return HPT_OK;
-    HIP_TRY(ctx, hipMalloc((void **)&dptr, bytes));
+    HIP_ALLOC(ctx, &dptr, bytes);
     HIP_TRY(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // copy-at-call-time semantics of CL_MEM_COPY_HOST_PTR
     return HPT_OK;
@@ -187,7 +198,7 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     const size_t samples_need = bytes_per_iteration * (size_t)batch_alloc;
     if (samples_need > ctx->samples_bytes) {
         if (ctx->d_samples) { HIP_TRY(ctx, hipFree(ctx->d_samples)); ctx->d_samples = nullptr; ctx->samples_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_samples, samples_need));
+        HIP_ALLOC(ctx, &ctx->d_samples, samples_need);
         ctx->samples_bytes = samples_need;
     }
     p.samples = ctx->d_samples;
@@ -206,7 +217,7 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     size_t spill_need = (size_t)(depth - cap) * (size_t)(blocks_max * kBlock) * sizeof(uint2);
     if (spill_need > ctx->spill_bytes) {
         if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_spill, spill_need));
+        HIP_ALLOC(ctx, &ctx->d_spill, spill_need);
         ctx->spill_bytes = spill_need;
     }
     p.spill = ctx->d_spill;
@@ -254,9 +265,11 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     hpt_ctx *ctx = new hpt_ctx;
     ctx->device = device; ctx->width = width; ctx->height = height;
     auto bail = [&](const char *what, hipError_t err) {
-        fail(nullptr, HPT_ERR_DEVICE, "%s: %s", what, hipGetErrorString(err));
+        const int code = err == hipErrorOutOfMemory ? HPT_ERR_NOMEM : HPT_ERR_DEVICE;
+        (void)hipGetLastError();          // the failed call's error is reported here; do not leave it for a later launch check
+        fail(nullptr, code, "%s: %s", what, hipGetErrorString(err));
         hpt_destroy(ctx);
-        return HPT_ERR_DEVICE;
+        return code;
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     hipDeviceProp_t prop;
@@ -417,7 +430,7 @@ int hpt_set_camera(hpt_ctx *ctx, const hpt_camera *camera) {
 
 int hpt_set_config(hpt_ctx *ctx, const hpt_config *cfg) {
     if (!ctx || !cfg) return HPT_ERR_INVALID;
-    if (cfg->max_depth < 0) return fail(ctx, HPT_ERR_INVALID, "max_depth %d", cfg->max_depth);
+    if (cfg->max_depth < 1) return fail(ctx, HPT_ERR_INVALID, "max_depth %d: a path has at least its camera ray", cfg->max_depth);
     ctx->cfg = *cfg;
     return HPT_OK;
 }
@@ -477,7 +490,7 @@ int hpt_first_bounce(hpt_ctx *ctx) {
     if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
     const size_t npx = (size_t)ctx->width * ctx->height;
     if (!ctx->d_iter) {
-        HIP_TRY(ctx, hipMalloc(&ctx->d_iter, npx * (6 * 16 + 2 * 8 + 4 + 16)));
+        HIP_ALLOC(ctx, &ctx->d_iter, npx * (6 * 16 + 2 * 8 + 4 + 16));
         char *q = (char *)ctx->d_iter;                       // 16-B members first: every array stays aligned
         ctx->iter.cur_a = (float4 *)q; q += npx * 16; ctx->iter.cur_b = (float4 *)q; q += npx * 16;
         ctx->iter.cur_c = (float4 *)q; q += npx * 16; ctx->iter.c_a = (float4 *)q; q += npx * 16;

@@ -232,8 +232,15 @@ def test_error_reporting():
     be.set_scene(s["primitives"], s["materials"]); be.set_camera(s["camera"])
     with pytest.raises(api.HptError, match="triangles are uploaded"):
         be.kernel_execute(0)
-    with pytest.raises(api.HptError):
+    with pytest.raises(api.HptError) as e:
         be.set_shard(3, 2)
+    assert e.value.status == -1                           # HPT_ERR_INVALID
+    with pytest.raises(api.HptError, match="max_depth"):
+        be.set_config(dict(max_depth=0, rr_start=3, diffuse_scale=2.0, seed=1))
+    with pytest.raises(api.HptError) as e:                # 2 x 480 GB of staging images: more than the GPU has
+        api.Backend(200000, 200000)
+    assert e.value.status == -3                           # HPT_ERR_NOMEM, and the partly built context is gone
+    api.Backend(32, 32).close()                           # the device is still usable
 
 
 def test_pathtracer_facade_matches_oracle():
