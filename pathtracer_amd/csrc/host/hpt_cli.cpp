@@ -4,7 +4,9 @@
 //
 //   hpt_cli --obj model.obj [--w 100 --h 100] [--spp 16] [--depth 15] [--device 0] [--out image.png|.ppm]
 //           [--light cx cy cz radius intensity]   (adds an emissive sphere; triangles cannot emit)
-//           [--progressive]                       (one render() per sample, like the viewer's idle loop)
+//           [--progressive]                       (one render() per sample)
+//           [--live N]                            (the viewer's frame loop, main.cpp:121-151: first bounce cached,
+//                                                  then N x { iterative_render(); reconstruct(); })
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +24,7 @@ static hpt_float4 f4(float x, float y, float z, float w) { hpt_float4 r; r.x = x
 
 int main(int argc, char **argv) {
     std::string obj, out = "out.png";
-    int w = 100, h = 100, spp = 16, depth = 15, device = 0;      // window 100x100: main.cpp:41-42
+    int w = 100, h = 100, spp = 16, depth = 15, device = 0, live = 0;      // window 100x100: main.cpp:41-42
     bool progressive = false, have_light = false;
     float light[5] = {0, -150, -40, 40, 10};
     for (int i = 1; i < argc; i++) {
@@ -35,10 +37,11 @@ int main(int argc, char **argv) {
         else if (!std::strcmp(argv[i], "--depth")) { need(1); depth = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--device")) { need(1); device = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--progressive")) progressive = true;
+        else if (!std::strcmp(argv[i], "--live")) { need(1); live = std::atoi(argv[++i]); }
         else if (!std::strcmp(argv[i], "--light")) { need(5); for (int k = 0; k < 5; k++) light[k] = (float)std::atof(argv[++i]); have_light = true; }
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
-    if (obj.empty()) { std::fprintf(stderr, "usage: hpt_cli --obj model.obj [--w W --h H --spp N --depth D --out file.png --light cx cy cz r e --progressive]\n"); return 2; }
+    if (obj.empty()) { std::fprintf(stderr, "usage: hpt_cli --obj model.obj [--w W --h H --spp N --depth D --out file.png --light cx cy cz r e --progressive --live N]\n"); return 2; }
 
     Pathtracer pt(w, h, device);
     if (!pt.ok()) { std::fprintf(stderr, "hpt_cli: %s\n", pt.error()); return 1; }
@@ -64,7 +67,11 @@ int main(int argc, char **argv) {
 
     t0 = std::chrono::steady_clock::now();
     Pixel *img = nullptr;
-    if (progressive) for (int s = 0; s < spp; s++) img = pt.render();
+    if (live > 0) {
+        pt.iterative_render_first_bounce();
+        for (int k = 0; k < live; k++) { pt.iterative_render(); pt.reconstruct(); }
+        img = pt.get_image();
+    } else if (progressive) for (int s = 0; s < spp; s++) img = pt.render();
     else img = pt.render(spp);
     double t_render = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!img) { std::fprintf(stderr, "hpt_cli: render failed: %s\n", pt.error()); return 1; }

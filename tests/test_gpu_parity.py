@@ -402,3 +402,13 @@ def test_cli_obj_to_png_end_to_end(tmp_path):
         want = orc.tonemap(o.render(0, 3)[0]).reshape(64, 64, 3)
         got = np.asarray(Image.open(str(out)).convert("RGB"))
         assert np.array_equal(got, want)
+    # the viewer's frame loop: first bounce cached, 7 x (one bounce; fold the finished paths)
+    r = subprocess.run([os.path.join(ROOT, "pathtracer_amd", "hpt_cli"), "--obj", str(obj), "--w", "64", "--h", "64", "--live", "7",
+                        "--depth", "4", "--out", str(out), "--light"] + [repr(x) for x in light],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want = np.zeros((64 * 64, 3), np.float32)
+    o.iter_first_bounce()
+    for _ in range(7):
+        o.iter_bounce(); o.iter_reconstruct(want)
+    assert np.array_equal(np.asarray(Image.open(str(out)).convert("RGB")), orc.tonemap(want).reshape(64, 64, 3))
