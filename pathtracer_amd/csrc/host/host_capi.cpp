@@ -2,6 +2,7 @@
 // reader, image writer, Pathtracer facade) so that Python tests and bench.py
 // can drive exactly the code a C++ application links.
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "bvh.hpp"
@@ -47,13 +48,26 @@ int hpt_host_build_bvh(const float *verts, int n, hpt_bvh_bbox *bbox, hpt_bvh_in
     return nn;
 }
 
-// Returns the number of vertices (3 per triangle), -1 on failure. out may be NULL to count.
+// Returns the number of vertices (3 per triangle), -1 on failure.  out may be NULL to count: the parsed list
+// is then kept (per thread) for the following call with the same path, so count + fetch parses the file once.
 long hpt_host_load_obj(const char *path, float *out_xyz, long cap_vertices) {
+    static thread_local std::string kept_path;
+    static thread_local std::vector<Vec3f> kept;
     std::vector<Vec3f> v;
-    if (!load_obj(path, v)) return -1;
-    if (out_xyz)
-        for (long i = 0; i < (long)v.size() && i < cap_vertices; i++) { out_xyz[3 * i] = v[i][0]; out_xyz[3 * i + 1] = v[i][1]; out_xyz[3 * i + 2] = v[i][2]; }
-    return (long)v.size();
+    if (out_xyz && !kept_path.empty() && kept_path == path) v.swap(kept);
+    else if (!load_obj(path, v)) { kept_path.clear(); kept.clear(); return -1; }
+    kept_path.clear(); kept.clear(); kept.shrink_to_fit();
+    const long n = (long)v.size();
+    if (out_xyz) {
+        const long m = n < cap_vertices ? n : cap_vertices;
+        parallel_chunks(build_threads(), m, [&](int, long b, long e) {
+            for (long i = b; i < e; i++) { out_xyz[3 * i] = v[i][0]; out_xyz[3 * i + 1] = v[i][1]; out_xyz[3 * i + 2] = v[i][2]; }
+        });
+    } else {
+        kept_path = path;
+        kept.swap(v);
+    }
+    return n;
 }
 
 int hpt_host_save_png(const float *rgb, int width, int height, const char *path) {

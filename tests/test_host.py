@@ -50,6 +50,45 @@ def test_host_bvh_parallel_build_is_thread_invariant(monkeypatch, name, kw, thre
     assert np.array_equal(b["order"], oo)
 
 
+def test_obj_reader_parallel_chunks(tmp_path, monkeypatch):
+    """Files over 1 MB are parsed in line-aligned chunks by several threads: interleaved `v`/`f` lines, negative
+    (relative) indices, polygons, `a/b/c` tokens, comments and CRLF line ends must give what a sequential
+    parse gives, whatever the thread count; a face naming a vertex that follows it is rejected."""
+    rng = np.random.default_rng(5)
+    lines, verts, want = [], [], []
+    for blk in range(4000):
+        for _ in range(int(rng.integers(3, 9))):
+            v = rng.uniform(-50, 50, 3).astype(np.float32)
+            verts.append(v)
+            lines.append("v %.9g %.9g %.9g%s" % (v[0], v[1], v[2], "\r" if blk % 7 == 0 else ""))
+        if blk % 5 == 0:
+            lines.append("# comment %d" % blk)
+        for _ in range(int(rng.integers(1, 6))):
+            k = int(rng.integers(3, 6))
+            idx = rng.integers(1, len(verts) + 1, k)
+            if rng.random() < 0.5:
+                toks = ["%d" % (i - len(verts) - 1) for i in idx]              # negative = relative to the vertices so far
+            else:
+                toks = ["%d/%d/%d" % (i, i, i) for i in idx]
+            lines.append("f " + " ".join(toks))
+            for j in range(2, k):
+                want += [verts[idx[0] - 1], verts[idx[j - 1] - 1], verts[idx[j] - 1]]
+    text = "\n".join(lines) + "\n"
+    text = text * 1 + "# padding\n" * max(0, (1200000 - len(text)) // 10)
+    p = tmp_path / "big.obj"
+    p.write_text(text)
+    assert p.stat().st_size > (1 << 20)
+    want = np.array(want, np.float32)
+    for threads in (1, 7, 16):
+        monkeypatch.setenv("HPT_BUILD_THREADS", str(threads))
+        got = api.load_obj(str(p))
+        assert got.shape == want.shape and np.array_equal(got, want), threads
+    q = tmp_path / "fwd.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nf 1 2 3\nv 0 1 0\n" + "# padding\n" * 120000)
+    with pytest.raises(api.HptError):
+        api.load_obj(str(q))
+
+
 def test_host_bvh_rejects_small_input():
     with pytest.raises(api.HptError):
         api.build_bvh(np.zeros((11, 3, 3), np.float32))
