@@ -71,6 +71,7 @@ struct hpt_ctx {
     int tris_per_trip = 8;
     int node_repeat_min = 24;
     int fetch_chunk = 1;             // 1: lanes that fetch together get adjacent pixels (coherent camera rays); larger chunks lose (r01_tuning.md)
+    int fetch_threshold = 32;        // iter_trace_kernel's FETCH step threshold (HPT_FETCH_THRESHOLD overrides)
     int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
     size_t spill_bytes = 0;
@@ -167,12 +168,36 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     p.tris_per_trip = ctx->tris_per_trip;
     p.node_repeat_min = ctx->node_repeat_min;
     p.fetch_chunk = ctx->fetch_chunk;
+    p.fetch_threshold = ctx->fetch_threshold;
     return HPT_OK;
 }
 
 size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
     int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
     return (size_t)depth * block * sizeof(uint2);
+}
+
+// Launch shape of a persistent traversal kernel (render_kernel, iter_trace_kernel): LDS for the capped
+// traversal stack, as many blocks as stay resident, HBM overflow of the stack sized for that grid.
+int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t &lds, long &blocks_max) {
+    const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
+    const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
+    lds = (size_t)cap * kBlock * sizeof(uint2);
+    HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds));
+    if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: %zu B of LDS per block", lds);
+    if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
+    blocks_max = (long)per_cu * ctx->n_cu;
+    p.stack_cap = cap;
+    size_t spill_need = (size_t)(depth - cap) * (size_t)(blocks_max * kBlock) * sizeof(uint2);
+    if (spill_need > ctx->spill_bytes) {
+        if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
+        HIP_ALLOC(ctx, &ctx->d_spill, spill_need);
+        ctx->spill_bytes = spill_need;
+    }
+    p.spill = ctx->d_spill;
+    return HPT_OK;
 }
 
 // One render = one or more launches of render_kernel (each over a batch of iterations whose samples fit the
@@ -203,24 +228,8 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     }
     p.samples = ctx->d_samples;
 
-    const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
-    const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
-    size_t lds = (size_t)cap * kBlock * sizeof(uint2);
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // persistent grid: as many blocks as stay resident (LDS stack and VGPRs bound it), at most the work
-    int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel, kBlock, lds));
-    if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: %zu B of LDS per block", lds);
-    if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
-    const long blocks_max = (long)per_cu * ctx->n_cu;
-    p.stack_cap = cap;
-    size_t spill_need = (size_t)(depth - cap) * (size_t)(blocks_max * kBlock) * sizeof(uint2);
-    if (spill_need > ctx->spill_bytes) {
-        if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
-        HIP_ALLOC(ctx, &ctx->d_spill, spill_need);
-        ctx->spill_bytes = spill_need;
-    }
-    p.spill = ctx->d_spill;
+    size_t lds; long blocks_max;
+    if ((rc = prepare_persistent(ctx, (const void *)render_kernel, p, lds, blocks_max))) return rc;
 
     const bool single = total <= batch_alloc;     // then the events bracket render_kernel alone
     if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -280,6 +289,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
     if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->fetch_chunk = v; }
+    if (const char *e = getenv("HPT_FETCH_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->fetch_threshold = v; }
     if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
     size_t img = (size_t)width * height * 3 * sizeof(float);
@@ -473,40 +483,57 @@ int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_p
 }
 
 // ---- iterative pipeline -------------------------------------------------------------------------------
-static int iter_launch_params(hpt_ctx *ctx, RenderParams &p, unsigned &blocks, size_t &lds) {
+static const size_t kIterBytesPerPixel = 7 * 16 + 3 * 8 + 4;    // 7 float4, 2 uint2 + 1 int2, 1 int32
+
+static int iter_launch_params(hpt_ctx *ctx, RenderParams &p, unsigned &blocks) {
     int rc = fill_params(ctx, p, nullptr, 0, 1, 0);
     if (rc) return rc;
     if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
         return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
     blocks = (p.n_slots + kBlock - 1) / kBlock;
-    lds = stack_lds_bytes(ctx, kBlock);
+    return HPT_OK;
+}
+
+// traversal half of a call: persistent iter_trace_kernel over this shard's pixel slots
+static int iter_trace(hpt_ctx *ctx, RenderParams &p, int first) {
+    size_t lds; long blocks_max;
+    int rc = prepare_persistent(ctx, (const void *)iter_trace_kernel, p, lds, blocks_max);
+    if (rc) return rc;
+    long blocks = blocks_max;
+    long need = ((long)p.n_slots + kBlock - 1) / kBlock;
+    if (blocks > need) blocks = need;
+    p.spill_stride = (uint32_t)(blocks * kBlock);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(iter_trace_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
+    HIP_TRY(ctx, hipGetLastError());
     return HPT_OK;
 }
 
 int hpt_first_bounce(hpt_ctx *ctx) {
     int rc = bind(ctx);
     if (rc) return rc;
-    RenderParams p; unsigned blocks; size_t lds;
-    if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
+    RenderParams p; unsigned blocks;
+    if ((rc = iter_launch_params(ctx, p, blocks))) return rc;
     const size_t npx = (size_t)ctx->width * ctx->height;
     if (!ctx->d_iter) {
-        HIP_ALLOC(ctx, &ctx->d_iter, npx * (6 * 16 + 2 * 8 + 4 + 16));
+        HIP_ALLOC(ctx, &ctx->d_iter, npx * kIterBytesPerPixel);
         char *q = (char *)ctx->d_iter;                       // 16-B members first: every array stays aligned
         ctx->iter.cur_a = (float4 *)q; q += npx * 16; ctx->iter.cur_b = (float4 *)q; q += npx * 16;
         ctx->iter.cur_c = (float4 *)q; q += npx * 16; ctx->iter.c_a = (float4 *)q; q += npx * 16;
         ctx->iter.c_b = (float4 *)q; q += npx * 16; ctx->iter.c_c = (float4 *)q; q += npx * 16;
         ctx->iter.contrib = (float4 *)q; q += npx * 16;
         ctx->iter.cur_d = (uint2 *)q; q += npx * 8; ctx->iter.c_d = (uint2 *)q; q += npx * 8;
+        ctx->iter.hit = (int2 *)q; q += npx * 8;
         ctx->iter.completed = (int32_t *)q;
     }
     // pixels outside the shard keep zeroed state (count 0, no contribution)
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_iter, 0, npx * (6 * 16 + 2 * 8 + 4 + 16), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_iter, 0, npx * kIterBytesPerPixel, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
     ctx->timed = false;
     ctx->iter_ready = 1; ctx->iter_pending = 0;
     if (blocks == 0) return HPT_OK;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)iter_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(iter_first_kernel, dim3(blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter);
+    if ((rc = iter_trace(ctx, p, 1))) return rc;
+    hipLaunchKernelGGL(iter_first_shade_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter);
     HIP_TRY(ctx, hipGetLastError());
     return HPT_OK;
 }
@@ -516,12 +543,12 @@ int hpt_bounce(hpt_ctx *ctx) {
     if (rc) return rc;
     if (!ctx->iter_ready) return fail(ctx, HPT_ERR_INVALID, "hpt_bounce before hpt_first_bounce");
     if (ctx->iter_pending) return fail(ctx, HPT_ERR_INVALID, "contributions of the previous hpt_bounce are not folded yet: call hpt_reconstruct_paths");
-    RenderParams p; unsigned blocks; size_t lds;
-    if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
+    RenderParams p; unsigned blocks;
+    if ((rc = iter_launch_params(ctx, p, blocks))) return rc;
     ctx->iter_pending = 1;
     if (blocks == 0) return HPT_OK;
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)iter_bounce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(iter_bounce_kernel, dim3(blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter);
+    if ((rc = iter_trace(ctx, p, 0))) return rc;
+    hipLaunchKernelGGL(iter_bounce_shade_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter);
     HIP_TRY(ctx, hipGetLastError());
     return HPT_OK;
 }
@@ -531,8 +558,8 @@ int hpt_reconstruct_paths(hpt_ctx *ctx, float *d_image) {
     if (rc) return rc;
     if (!d_image) return fail(ctx, HPT_ERR_INVALID, "bad reconstruct_paths arguments");
     if (!ctx->iter_ready) return fail(ctx, HPT_ERR_INVALID, "hpt_reconstruct_paths before hpt_first_bounce");
-    RenderParams p; unsigned blocks; size_t lds;
-    if ((rc = iter_launch_params(ctx, p, blocks, lds))) return rc;
+    RenderParams p; unsigned blocks;
+    if ((rc = iter_launch_params(ctx, p, blocks))) return rc;
     ctx->iter_pending = 0;
     if (blocks == 0) return HPT_OK;
     hipLaunchKernelGGL(iter_reconstruct_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter, d_image);

@@ -66,6 +66,7 @@ struct RenderParams {
     int32_t batch;                   // iterations in this launch: spp_base .. spp_base + batch - 1
     int32_t spp_base;
     int32_t fetch_chunk;             // work items a lane reserves per atomic (scheduling only)
+    int32_t fetch_threshold;         // iter_trace_kernel: lanes that must want a new ray before the wave fetches (scheduling only)
 };
 
 struct Ray { f3 o, d; };
@@ -710,7 +711,8 @@ __global__ void __launch_bounds__(256) primary_hits_kernel(const RenderParams p,
 // pixel's contribution, counts as completed, and the pixel restarts from the cache; reconstruct folds fresh
 // contributions into the per-pixel running mean.  Path n of a pixel draws from key(seed, pixel, n), counter
 // continuing after the cached bounce.  All per-pixel state stays in HBM (the reference moves it over PCIe
-// both ways on every call).  One thread per pixel slot of the shard, one ray per thread per launch.
+// both ways on every call).  Each call is a traversal kernel (persistent, the step functions of render_kernel)
+// followed by a shading kernel (one thread per pixel slot of the shard).
 struct IterState {
     float4 *cur_a, *cur_b, *cur_c;   // current path: {o.xyz, weight.x} {d.xyz, weight.y} {color.xyz, weight.z}
     uint2 *cur_d;                    // {rng counter, bounces done}
@@ -718,81 +720,145 @@ struct IterState {
     uint2 *c_d;                      // {rng counter, 1 if bounce 0 ended the path}
     int32_t *completed;              // paths folded per pixel (the reference's iteration_memory)
     float4 *contrib;                 // {rgb of the last finished path, 1 if it waits for reconstruct}
+    int2 *hit;                       // {hit id, bits of t} of the ray traced by the current call
 };
 
-__device__ __forceinline__ void iter_count_rays(const RenderParams &p, int counter, bool traced) {
+// Traversal half of one call: a persistent grid pulls the shard's pixel slots in chunks (one atomic per wave
+// per chunk, lanes of a wave get neighbouring pixels), traces each pixel's current ray with the NODE / TRI
+// steps of render_kernel and stores (hit, t).  first != 0: the ray is the camera ray of jitter cell 0, which
+// is generated here and left in cur_a/cur_b (origin, direction) and cur_d.x (rng counter after the jitter).
+// Pixels whose cached bounce already ended the path trace nothing.
+__global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const RenderParams p, const IterState it, int first) {
+    uint2 *stack = hpt_lds_stack + threadIdx.x;
+    const int stride = blockDim.x;
+    uint2 *const spill = p.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    const unsigned n = p.n_slots;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    unsigned chunk = (n / (waves * 4u)) & ~63u;
+    chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
+    unsigned chunk_next = 0, chunk_end = 0;              // wave-uniform
+    unsigned traced = 0;
+    int gid = -1;
+    Trav tv;
+    tv.oxy = hpt_v2f{0, 0}; tv.ozix = hpt_v2f{0, 0}; tv.iyz = hpt_v2f{0, 0}; tv.rd = mk3(0, 0, 1);
+    tv.t = 1000.0f; tv.hit = HPT_HIT_MISS; tv.cur = HPT_REF_DONE; tv.sp = 0; tv.flags = 0;
+    for (;;) {
+        const int nF = __popcll(hpt_ballot(tv.cur == HPT_REF_DONE));
+        const int nN = __popcll(hpt_ballot((unsigned)tv.cur < (unsigned)HPT_REF_IDLE));
+        const int nT = __popcll(hpt_ballot(tv.cur < 0));
+        if (nF + nN + nT == 0) break;
+        if (nF >= p.fetch_threshold || nN + nT == 0) {
+            bool want = tv.cur == HPT_REF_DONE;
+            if (want && gid >= 0) it.hit[gid] = make_int2(tv.hit, __float_as_int(tv.t));
+            if (want) gid = -1;
+            for (;;) {
+                const unsigned long long need = hpt_ballot(want);
+                if (need == 0ull) break;
+                if (chunk_next >= chunk_end) {
+                    unsigned at = 0;
+                    if (lane == 0u) at = atomicAdd(p.work_counter, chunk);
+                    at = __builtin_amdgcn_readfirstlane(at);
+                    if (at >= n) { if (want) tv.cur = HPT_REF_IDLE; break; }
+                    chunk_next = at;
+                    chunk_end = (n - at) < chunk ? n : at + chunk;
+                }
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+                const unsigned avail = chunk_end - chunk_next;
+                if (want && rank < avail) {
+                    const int g = work_to_pixel(p, chunk_next + rank);
+                    if (g >= 0 && (first || it.c_d[g].y == 0u)) { gid = g; want = false; }
+                }
+                const unsigned cnt = (unsigned)__popcll(need);
+                chunk_next += cnt < avail ? cnt : avail;
+            }
+            if (tv.cur == HPT_REF_DONE && gid >= 0) {
+                f3 o, d;
+                if (first) {
+                    const uint32_t key = path_key(p.seed, (uint32_t)gid, 0u);
+                    uint32_t ctr = 0;
+                    const Ray r = camera_ray(p, gid, 0, key, ctr);
+                    o = r.o; d = r.d;
+                    it.cur_a[gid] = make_float4(o.x, o.y, o.z, 1.0f);
+                    it.cur_b[gid] = make_float4(d.x, d.y, d.z, 1.0f);
+                    it.cur_d[gid] = make_uint2(ctr, 0u);
+                } else {
+                    const float4 a = it.cur_a[gid], b = it.cur_b[gid];
+                    o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z);
+                }
+                traced++;
+                trav_start(p, tv, o, d);
+            }
+        } else if (nT > nN) {
+            trav_tri_steps(p, tv, stack, stride, spill);
+        } else {
+            trav_node_steps(p, tv, stack, stride, spill);
+        }
+    }
     __shared__ unsigned block_rays;
     if (threadIdx.x == 0) block_rays = 0;
     __syncthreads();
-    const unsigned long long m = hpt_ballot(traced);
-    if ((threadIdx.x & 63u) == 0u && m) atomicAdd(&block_rays, (unsigned)__popcll(m));
+    if (traced) atomicAdd(&block_rays, traced);
     __syncthreads();
-    if (threadIdx.x == 0 && block_rays) atomicAdd(p.counters + counter, (unsigned long long)block_rays);
+    if (threadIdx.x == 0 && block_rays) atomicAdd(p.counters + (first ? 0 : 1), (unsigned long long)block_rays);
 }
 
-__global__ void __launch_bounds__(256) iter_first_kernel(const RenderParams p, const IterState it) {
-    uint2 *stack = hpt_lds_stack + threadIdx.x;
+// Shading half of hpt_first_bounce: bounce 0 of every pixel from the stored camera ray and hit; fills the cache
+// and starts path 0 from it.
+__global__ void __launch_bounds__(256) iter_first_shade_kernel(const RenderParams p, const IterState it) {
     const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int gid = slot < p.n_slots ? work_to_pixel(p, slot) : -1;
-    if (gid >= 0) {
-        const uint32_t key = path_key(p.seed, (uint32_t)gid, 0u);
-        uint32_t ctr = 0;
-        Ray r = camera_ray(p, gid, 0, key, ctr);
-        f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
-        float t;
-        const int id = closest_hit(p, r.o, r.d, t, stack, blockDim.x);
-        const bool go_on = shade_bounce(p, id, t, r, key, ctr, 0, color, weight);
-        const bool finished = !go_on || 1 >= p.max_depth;
-        const float4 a = make_float4(r.o.x, r.o.y, r.o.z, weight.x), b = make_float4(r.d.x, r.d.y, r.d.z, weight.y);
-        const float4 c = make_float4(color.x, color.y, color.z, weight.z);
-        it.c_a[gid] = a; it.c_b[gid] = b; it.c_c[gid] = c; it.c_d[gid] = make_uint2(ctr, finished ? 1u : 0u);
-        it.cur_a[gid] = a; it.cur_b[gid] = b; it.cur_c[gid] = c; it.cur_d[gid] = make_uint2(ctr, 1u);
-        it.completed[gid] = 0;
-        it.contrib[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    iter_count_rays(p, 0, gid >= 0);
+    if (gid < 0) return;
+    const uint32_t key = path_key(p.seed, (uint32_t)gid, 0u);
+    const float4 ra = it.cur_a[gid], rb = it.cur_b[gid];
+    uint32_t ctr = it.cur_d[gid].x;
+    const int2 h = it.hit[gid];
+    Ray r; r.o = mk3(ra.x, ra.y, ra.z); r.d = mk3(rb.x, rb.y, rb.z);
+    f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
+    const bool go_on = shade_bounce(p, h.x, __int_as_float(h.y), r, key, ctr, 0, color, weight);
+    const bool finished = !go_on || 1 >= p.max_depth;
+    const float4 a = make_float4(r.o.x, r.o.y, r.o.z, weight.x), b = make_float4(r.d.x, r.d.y, r.d.z, weight.y);
+    const float4 c = make_float4(color.x, color.y, color.z, weight.z);
+    it.c_a[gid] = a; it.c_b[gid] = b; it.c_c[gid] = c; it.c_d[gid] = make_uint2(ctr, finished ? 1u : 0u);
+    it.cur_a[gid] = a; it.cur_b[gid] = b; it.cur_c[gid] = c; it.cur_d[gid] = make_uint2(ctr, 1u);
+    it.completed[gid] = 0;
+    it.contrib[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-__global__ void __launch_bounds__(256) iter_bounce_kernel(const RenderParams p, const IterState it) {
-    uint2 *stack = hpt_lds_stack + threadIdx.x;
+// Shading half of hpt_bounce.
+__global__ void __launch_bounds__(256) iter_bounce_shade_kernel(const RenderParams p, const IterState it) {
     const unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     const int gid = slot < p.n_slots ? work_to_pixel(p, slot) : -1;
-    bool traced = false;
-    if (gid >= 0) {
-        const uint2 cd = it.c_d[gid];
-        float4 c = it.cur_c[gid];
-        f3 color = mk3(c.x, c.y, c.z);
-        bool ended = cd.y != 0u;                 // the cached bounce already ended the path: one path per call
+    if (gid < 0) return;
+    const uint2 cd = it.c_d[gid];
+    float4 c = it.cur_c[gid];
+    f3 color = mk3(c.x, c.y, c.z);
+    bool ended = cd.y != 0u;                     // the cached bounce already ended the path: one path per call
+    if (!ended) {
+        const float4 a = it.cur_a[gid], b = it.cur_b[gid];
+        const uint2 d = it.cur_d[gid];
+        const int2 h = it.hit[gid];
+        const uint32_t key = path_key(p.seed, (uint32_t)gid, (uint32_t)it.completed[gid]);
+        uint32_t ctr = d.x;
+        int bounce = (int)d.y;
+        Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(b.x, b.y, b.z);
+        f3 weight = mk3(a.w, b.w, c.w);
+        const bool go_on = shade_bounce(p, h.x, __int_as_float(h.y), r, key, ctr, bounce, color, weight);
+        bounce++;
+        ended = !go_on || bounce >= p.max_depth;
         if (!ended) {
-            const float4 a = it.cur_a[gid], b = it.cur_b[gid];
-            const uint2 d = it.cur_d[gid];
-            const int n = it.completed[gid];
-            const uint32_t key = path_key(p.seed, (uint32_t)gid, (uint32_t)n);
-            uint32_t ctr = d.x;
-            int bounce = (int)d.y;
-            Ray r; r.o = mk3(a.x, a.y, a.z); r.d = mk3(b.x, b.y, b.z);
-            f3 weight = mk3(a.w, b.w, c.w);
-            float t;
-            const int id = closest_hit(p, r.o, r.d, t, stack, blockDim.x);
-            traced = true;
-            const bool go_on = shade_bounce(p, id, t, r, key, ctr, bounce, color, weight);
-            bounce++;
-            ended = !go_on || bounce >= p.max_depth;
-            if (!ended) {
-                it.cur_a[gid] = make_float4(r.o.x, r.o.y, r.o.z, weight.x);
-                it.cur_b[gid] = make_float4(r.d.x, r.d.y, r.d.z, weight.y);
-                it.cur_c[gid] = make_float4(color.x, color.y, color.z, weight.z);
-                it.cur_d[gid] = make_uint2(ctr, (unsigned)bounce);
-            }
-        }
-        if (ended) {
-            it.contrib[gid] = make_float4(color.x, color.y, color.z, 1.0f);
-            it.completed[gid] = it.completed[gid] + 1;
-            it.cur_a[gid] = it.c_a[gid]; it.cur_b[gid] = it.c_b[gid]; it.cur_c[gid] = it.c_c[gid];
-            it.cur_d[gid] = make_uint2(cd.x, 1u);
+            it.cur_a[gid] = make_float4(r.o.x, r.o.y, r.o.z, weight.x);
+            it.cur_b[gid] = make_float4(r.d.x, r.d.y, r.d.z, weight.y);
+            it.cur_c[gid] = make_float4(color.x, color.y, color.z, weight.z);
+            it.cur_d[gid] = make_uint2(ctr, (unsigned)bounce);
         }
     }
-    iter_count_rays(p, 1, traced);
+    if (ended) {
+        it.contrib[gid] = make_float4(color.x, color.y, color.z, 1.0f);
+        it.completed[gid] = it.completed[gid] + 1;
+        it.cur_a[gid] = it.c_a[gid]; it.cur_b[gid] = it.c_b[gid]; it.cur_c[gid] = it.c_c[gid];
+        it.cur_d[gid] = make_uint2(cd.x, 1u);
+    }
 }
 
 // image = (1/n)*contribution + ((n-1)/n)*image with n = the pixel's completed paths (pathtracer.cpp:200-217
