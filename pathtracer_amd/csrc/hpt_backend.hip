@@ -70,7 +70,7 @@ struct hpt_ctx {
     int shade_threshold = 32;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
     int tris_per_trip = 8;
     int node_repeat_min = 24;
-    int fetch_chunk = 1;             // 1: lanes that fetch together get adjacent pixels (coherent camera rays); larger chunks lose (r01_tuning.md)
+    int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
     int fetch_threshold = 32;        // iter_trace_kernel's FETCH step threshold (HPT_FETCH_THRESHOLD overrides)
     int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
@@ -215,7 +215,8 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     // iterations per launch: bounded by the sample buffer budget and by 32-bit work indices
     const size_t bytes_per_iteration = (size_t)p.n_slots * 3 * sizeof(float);
     long batch_max = (long)(ctx->sample_budget_bytes / bytes_per_iteration);
-    const long idx_max = (long)(0xFFFFFF00u / p.n_slots);
+    // 32-bit work indices, with headroom for the counter's overshoot (one chunk of <= 4096 per wave, < 2^16 waves)
+    const long idx_max = (long)(0xF0000000u / p.n_slots);
     if (batch_max > idx_max) batch_max = idx_max;
     if (batch_max < 1) batch_max = 1;
     const int total = spp_end - spp_begin;
@@ -288,7 +289,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
-    if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->fetch_chunk = v; }
+    if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->fetch_chunk = v; }
     if (const char *e = getenv("HPT_FETCH_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->fetch_threshold = v; }
     if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }

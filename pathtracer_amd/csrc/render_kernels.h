@@ -65,7 +65,7 @@ struct RenderParams {
     uint32_t n_slots;                // pixel slots of this shard = local tiles * 64
     int32_t batch;                   // iterations in this launch: spp_base .. spp_base + batch - 1
     int32_t spp_base;
-    int32_t fetch_chunk;             // work items a lane reserves per atomic (scheduling only)
+    int32_t fetch_chunk;             // work items a wave reserves per atomic, <= 4096 (scheduling only)
     int32_t fetch_threshold;         // iter_trace_kernel: lanes that must want a new ray before the wave fetches (scheduling only)
 };
 
@@ -591,7 +591,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 #endif
 
     int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path
-    unsigned work_next = 0, work_left = 0;   // items this lane has reserved from the work counter
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned chunk_next = 0, chunk_end = 0;  // work items this WAVE has reserved from the work counter (wave-uniform)
+    bool exhausted = false;                  // the work counter has passed n_work (wave-uniform)
     unsigned out_idx = 0;                // sample slot of the current path: (s - spp_base) * n_slots + pixel slot
     uint32_t key = 0, ctr = 0;
     f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
@@ -617,9 +619,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 #endif
 
         if (nS >= p.shade_threshold || nN + nT == 0) {
-            if (wantS) {
+            {
                 Ray r;
-                if (b >= 0) {            // a ray has just finished: one bounce of the path loop
+                if (wantS && b >= 0) {   // a ray has just finished: one bounce of the path loop
                     if (b == 0) n_primary++; else n_bounce++;
                     r.o = mk3(tv.oxy.x, tv.oxy.y, tv.ozix.x); r.d = tv.rd;
                     bool go_on = shade_bounce(p, tv.hit, tv.t, r, key, ctr, b, color, weight);
@@ -631,22 +633,37 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         b = -1;
                     }
                 }
-                if (b < 0) {             // next path of this shard: (tile, iteration, pixel in tile)
-                    for (;;) {
-                        if (work_left == 0) {    // reserve fetch_chunk consecutive items with one atomic
-                            work_next = atomicAdd(p.work_counter, (unsigned)p.fetch_chunk);
-                            work_left = (unsigned)p.fetch_chunk;
-                        }
-                        const unsigned work = work_next;
-                        if (work >= p.n_work) { tv.cur = HPT_REF_IDLE; break; }
-                        work_next++; work_left--;
+                // next path of this shard: (tile, iteration, pixel in tile).  Work items are reserved per WAVE in
+                // chunks of fetch_chunk (one atomic per chunk on the single work counter) and handed to the lanes
+                // in order, so lanes that fetch together still get adjacent pixels of one iteration.  (Wave-uniform
+                // control flow: every lane takes part in the votes, lane 0 does the atomic.)
+                bool want = wantS && b < 0;
+                for (;;) {
+                    const unsigned long long need = hpt_ballot(want);
+                    if (need == 0ull) break;
+                    if (chunk_next >= chunk_end) {
+                        // after the first miss a wave never touches the counter again, so the counter overshoots
+                        // n_work by at most waves * fetch_chunk (the host keeps that much headroom below 2^32)
+                        unsigned at = 0xffffffffu;
+                        if (!exhausted && lane == 0u) at = atomicAdd(p.work_counter, (unsigned)p.fetch_chunk);
+                        at = __builtin_amdgcn_readfirstlane(at);
+                        if (at >= p.n_work) { exhausted = true; if (want) tv.cur = HPT_REF_IDLE; break; }
+                        chunk_next = at;
+                        chunk_end = (p.n_work - at) < (unsigned)p.fetch_chunk ? p.n_work : at + (unsigned)p.fetch_chunk;
+                    }
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+                    const unsigned avail = chunk_end - chunk_next;
+                    if (want && rank < avail) {
+                        const unsigned work = chunk_next + rank;
                         const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
                         const unsigned slot = tile * 64u + (work & 63u);
                         gid = work_to_pixel(p, slot);
-                        if (gid >= 0) { s = p.spp_base + (int)sl; out_idx = sl * p.n_slots + slot; break; }
+                        if (gid >= 0) { s = p.spp_base + (int)sl; out_idx = sl * p.n_slots + slot; want = false; }
                     }
+                    const unsigned cnt = (unsigned)__popcll(need);
+                    chunk_next += cnt < avail ? cnt : avail;
                 }
-                if (tv.cur != HPT_REF_IDLE) {
+                if (wantS && tv.cur != HPT_REF_IDLE) {
                     if (b < 0) {         // camera ray of (pixel, iteration)
                         key = path_key(p.seed, (uint32_t)gid, (uint32_t)s);
                         ctr = 0;
