@@ -67,7 +67,7 @@ struct hpt_ctx {
     bool timed = false;
     int n_cu = 256;
     int grid_waves = 0;
-    int shade_threshold = 32;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
+    int shade_threshold = 24;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
     int tris_per_trip = 8;
     int node_repeat_min = 24;
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
