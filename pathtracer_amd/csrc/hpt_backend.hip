@@ -49,8 +49,15 @@ struct hpt_ctx {
     int root_ref = HPT_REF_DONE;
     float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
 
-    float4 *d_tris = nullptr;
+    float4 *d_tris = nullptr;        // wire-format triangles (shading reads the hit triangle's edges)
     int n_tris = 0;
+    // The traversal reads triangles as 80-B records of two consecutive triangles of a leaf (render_kernels.h),
+    // which needs both the triangle array and the tree: built lazily from these host copies, in either upload order.
+    std::vector<hpt_triangle> h_tris;
+    std::vector<WideNode> h_wide;    // leaf references still (first triangle << 6 | count-1)
+    int root_ref_tris = HPT_REF_DONE;
+    float4 *d_pairs = nullptr;
+    bool pairs_dirty = true;
     hpt_primitive *d_prims = nullptr;
     int n_prims = 0;
     hpt_material *d_mats = nullptr;
@@ -137,6 +144,47 @@ int n_tiles(const hpt_ctx *c) { return tiles_x(c) * tiles_y(c); }
 // tiles of the largest shard: every rank's slab has this many (all-gather wants equal sizes)
 int slab_tiles(const hpt_ctx *c) { return (n_tiles(c) + c->world - 1) / c->world; }
 
+// Builds the traversal's triangle records (two consecutive triangles of a leaf per 80 B, render_kernels.h) and
+// uploads the nodes with their leaf references re-pointed at them.  Leaves are numbered in node order, so a
+// near-first descent walks the records forward.
+int ensure_pairs(hpt_ctx *ctx) {
+    if (!ctx->pairs_dirty) return HPT_OK;
+    if (ctx->root_ref_tris == HPT_REF_DONE) { ctx->pairs_dirty = false; return HPT_OK; }     // no tree
+    if (ctx->max_leaf_end > ctx->n_tris) return HPT_OK;       // fill_params reports it
+    std::vector<WideNode> wide(ctx->h_wide);
+    std::vector<float> rec;
+    rec.reserve(((size_t)ctx->n_tris / 2 + wide.size() + 1) * 20);
+    auto repoint = [&](int32_t &ref) {
+        if (ref >= 0) return;
+        const int packed = ~ref, first = packed >> 6, n = (packed & 63) + 1;
+        const int first_pair = (int)(rec.size() / 20);
+        for (int i = 0; i < n; i += 2) {
+            float r[20];
+            for (int k = 0; k < 20; k++) r[k] = 0.0f;
+            for (int h = 0; h < 2 && i + h < n; h++) {
+                const hpt_triangle &t = ctx->h_tris[first + i + h];
+                float *f = r + (h ? 11 : 0);
+                f[0] = t.v1.x; f[1] = t.v1.y; f[2] = t.v1.z; f[3] = t.e1.x; f[4] = t.e1.y; f[5] = t.e1.z;
+                f[6] = t.e2.x; f[7] = t.e2.y; f[8] = t.e2.z;
+                const int32_t id = first + i + h;
+                memcpy(r + 9 + h, &id, 4);
+            }
+            rec.insert(rec.end(), r, r + 20);
+        }
+        ref = HPT_PAIR_REF(first_pair, n);
+    };
+    int32_t root = ctx->root_ref_tris;
+    repoint(root);
+    for (WideNode &w : wide) { repoint(w.ref0); repoint(w.ref1); }
+    if (rec.size() / 20 >= (size_t)(1 << 25)) return fail(ctx, HPT_ERR_BVH, "too many triangle records");
+    int rc = replace_buffer(ctx, ctx->d_nodes, wide.data(), wide.size() * sizeof(WideNode));
+    if (rc) return rc;
+    if ((rc = replace_buffer(ctx, ctx->d_pairs, rec.data(), rec.size() * sizeof(float)))) return rc;
+    ctx->root_ref = root;
+    ctx->pairs_dirty = false;
+    return HPT_OK;
+}
+
 int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, int spp_end, int raw) {
     if (!ctx->have_camera) return fail(ctx, HPT_ERR_INVALID, "hpt_set_camera has not been called");
     if (ctx->root_ref != HPT_REF_DONE && ctx->max_leaf_end > ctx->n_tris)
@@ -145,7 +193,10 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     if ((long)ctx->width * ctx->height >= (1L << 24))
         return fail(ctx, HPT_ERR_INVALID, "width*height must stay below 2^24 (pixel index is converted to float, "
                                           "initial_ray_kernel.cl:863)");
+    int rc_pairs = ensure_pairs(ctx);
+    if (rc_pairs) return rc_pairs;
     memset(&p, 0, sizeof p);
+    p.pairs = ctx->d_pairs;
     p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.mats = ctx->d_mats;
     p.image = d_image; p.hit_id = ctx->d_hit_id; p.hit_t = ctx->d_hit_t;
     p.work_counter = ctx->d_work; p.counters = ctx->d_counters;
@@ -313,7 +364,7 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);
-    (void)hipFree(ctx->d_iter);
+    (void)hipFree(ctx->d_iter); (void)hipFree(ctx->d_pairs);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -341,6 +392,8 @@ int hpt_upload_triangles(hpt_ctx *ctx, const hpt_triangle *triangles, int n_tria
     rc = replace_buffer(ctx, ctx->d_tris, triangles, (size_t)n_triangles * sizeof(hpt_triangle));
     if (rc) return rc;
     ctx->n_tris = n_triangles;
+    ctx->h_tris.assign(triangles, triangles + n_triangles);
+    ctx->pairs_dirty = true;
     return HPT_OK;
 }
 
@@ -353,7 +406,9 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
     if (rc) return rc;
     if (n_nodes < 0 || (n_nodes > 0 && (!bbox || !info))) return fail(ctx, HPT_ERR_INVALID, "bad BVH arrays");
     if (ctx->d_nodes) { HIP_TRY(ctx, hipFree(ctx->d_nodes)); ctx->d_nodes = nullptr; }
-    ctx->n_wide = 0; ctx->tree_depth = 0; ctx->max_leaf_end = 0; ctx->root_ref = HPT_REF_DONE;
+    ctx->n_wide = 0; ctx->tree_depth = 0; ctx->max_leaf_end = 0; ctx->root_ref = HPT_REF_DONE; ctx->root_ref_tris = HPT_REF_DONE;
+    ctx->h_wide.clear();
+    ctx->pairs_dirty = true;
     if (n_nodes == 0) return HPT_OK;
 
     auto leaf_ref = [&](int k, int &ref) -> int {
@@ -409,12 +464,12 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
         if (info[c0].nPrimitives > 0) { if ((rc = leaf_ref(c0, w.ref0))) return rc; } else w.ref0 = wide_of[c0];
         if (info[c1].nPrimitives > 0) { if ((rc = leaf_ref(c1, w.ref1))) return rc; } else w.ref1 = wide_of[c1];
     }
-    if (info[0].nPrimitives > 0) { if ((rc = leaf_ref(0, ctx->root_ref))) return rc; }
-    else ctx->root_ref = wide_of[0];
+    if (info[0].nPrimitives > 0) { if ((rc = leaf_ref(0, ctx->root_ref_tris))) return rc; }
+    else ctx->root_ref_tris = wide_of[0];
+    ctx->root_ref = ctx->root_ref_tris;                  // "there is a tree"; ensure_pairs() re-points a leaf root
     ctx->root_lo[0] = bbox[0].minboundsx; ctx->root_lo[1] = bbox[0].minboundsy; ctx->root_lo[2] = bbox[0].minboundsz;
     ctx->root_hi[0] = bbox[0].maxboundsx; ctx->root_hi[1] = bbox[0].maxboundsy; ctx->root_hi[2] = bbox[0].maxboundsz;
-    rc = replace_buffer(ctx, ctx->d_nodes, wide.data(), wide.size() * sizeof(WideNode));
-    if (rc) { ctx->root_ref = HPT_REF_DONE; return rc; }
+    ctx->h_wide.swap(wide);                              // uploaded by ensure_pairs() with leaf references re-pointed
     ctx->n_wide = n_wide;
     ctx->tree_depth = depth_max;
     return HPT_OK;

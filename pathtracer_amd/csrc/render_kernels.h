@@ -16,7 +16,7 @@
 
 // 64-byte node: the boxes of both children of one interior node of the
 // reference tree (child0 = node k+1, child1 = secondChildOffset, bvh.cpp:382-386).
-// ref >= 0: index of the child's own WideNode; ref < 0: leaf, ~ref = (first triangle << 6) | (count-1).
+// ref >= 0: index of the child's own WideNode; ref < 0: leaf, ~ref = (first triangle PAIR << 6) | (count-1).
 // Per axis one 16-B piece {lo of child 0, lo of child 1, hi of child 0, hi of child 1}: the two children's
 // plane distances come out of one v_pk_add_f32 + one v_pk_mul_f32 per register pair.
 struct __attribute__((aligned(64))) WideNode {
@@ -34,7 +34,8 @@ static_assert(sizeof(WideNode) == 64, "WideNode must be one 64-B line");
 
 struct RenderParams {
     const WideNode *nodes;
-    const float4 *tris;              // hpt_triangle[] viewed as 3 x float4
+    const float4 *tris;              // hpt_triangle[] viewed as 3 x float4 (shading: normal of the hit triangle)
+    const float4 *pairs;             // triangles as the traversal reads them: 80-B records of two (leaf references point here)
     const hpt_primitive *prims;
     const hpt_material *mats;
     float *image;                    // width*height*3
@@ -209,15 +210,12 @@ __device__ __forceinline__ void slab2_refform(float4 X, float4 Y, float4 Z, hpt_
 // Straight-line form: every quantity is computed as the reference computes it when it gets that
 // far, and the reference's early returns become one conjunction (a value the reference never
 // reaches cannot change the outcome, and NaN comparisons keep their reference polarity).
-__device__ __forceinline__ bool intersect_tri(const float4 *__restrict__ tris, int idx, f3 o, f3 d, float &t) {
-    const float4 *q = tris + 3 * (size_t)idx;
-    float4 v1 = q[0], e1 = q[1], e2 = q[2];
-    f3 edge1 = mk3(e1), edge2 = mk3(e2);
+__device__ __forceinline__ bool intersect_tri(f3 v1, f3 edge1, f3 edge2, f3 o, f3 d, float &t) {
     f3 pvec = cross3(d, edge2);
     float det = dot3(edge1, pvec);
     bool ok = !(fabsf(det) < HPT_EPSILON);
     float invDet = 1.0f / det;
-    f3 tvec = o - mk3(v1);
+    f3 tvec = o - v1;
     float u = dot3(tvec, pvec) * invDet;
     ok = ok && !(u < 0.0f || u > 1.0f);
     f3 qvec = cross3(tvec, edge1);
@@ -227,6 +225,18 @@ __device__ __forceinline__ bool intersect_tri(const float4 *__restrict__ tris, i
     ok = ok && (tt < t && tt > 0.0f);
     if (ok) t = tt;
     return ok;
+}
+
+// Triangles as the traversal reads them: two consecutive triangles of one leaf per 80-B record, each as
+// {v1, e1, e2} plus its index in the uploaded (leaf-order) array.  Five 16-B loads serve two triangle tests
+// (2.5 lane-loads per triangle instead of 3); a leaf with an odd count ends in a record whose second half is
+// never read.  Float slots: a = 0..8, id_a = 9, id_b = 10, b = 11..19.
+#define HPT_PAIR_FLOAT4S 5
+#define HPT_PAIR_REF(first_pair, n) (~(((first_pair) << 6) | ((n) - 1)))
+__device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ pairs, int pair, int half, f3 o, f3 d, float &t, int &id) {
+    const float *f = reinterpret_cast<const float *>(pairs + (size_t)HPT_PAIR_FLOAT4S * pair) + (half ? 11 : 0);
+    id = __float_as_int(reinterpret_cast<const float *>(pairs + (size_t)HPT_PAIR_FLOAT4S * pair)[9 + half]);
+    return intersect_tri(mk3(f[0], f[1], f[2]), mk3(f[3], f[4], f[5]), mk3(f[6], f[7], f[8]), o, d, t);
 }
 
 // ---- sphere / plane, ray_kernel.cl:524-602 ----
@@ -305,9 +315,11 @@ __device__ __forceinline__ int traverse(const RenderParams &p, f3 o, f3 d, float
             else pop = true;
         } else {
             int packed = ~cur;
-            int first = packed >> 6, n = (packed & 63) + 1;
-            for (int i = 0; i < n; i++)
-                if (intersect_tri(p.tris, first + i, o, d, t)) hit = first + i;
+            int first = packed >> 6, n = (packed & 63) + 1;     // first PAIR of the leaf, triangles in it
+            for (int i = 0; i < n; i++) {
+                int id;
+                if (intersect_pair_half(p.pairs, first + (i >> 1), i & 1, o, d, t, id)) hit = id;
+            }
             pop = true;
         }
         if (pop) {
@@ -492,14 +504,24 @@ __device__ __forceinline__ void trav_pop(const RenderParams &p, Trav &s, uint2 *
 }
 
 // TRI step: up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a
-// leaf).  A lane is in the TRI state exactly when cur < 0, so the state is re-read from cur, not carried.
+// leaf), two per iteration from one pair record.  A lane is in the TRI state exactly when cur < 0, so the state
+// is re-read from cur, not carried.  ~cur = (next pair << 6) | (triangles left - 1).
 __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
-    for (int k = 0; k < p.tris_per_trip; k++) {
+    for (int k = 0; k < p.tris_per_trip; k += 2) {
         if (s.cur < 0) {
-            const int packed = ~s.cur, idx = packed >> 6;
-            if (intersect_tri(p.tris, idx, mk3(s.oxy.x, s.oxy.y, s.ozix.x), s.rd, s.t)) s.hit = idx;
-            if ((packed & 63) == 0) trav_pop(p, s, stack, stride, spill);
-            else s.cur = ~(packed + 63);                  // next triangle, one fewer left
+            const int packed = ~s.cur, pair = packed >> 6, left = (packed & 63) + 1;
+            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.pairs) + (unsigned)pair * 80u);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+            const bool two = left >= 2;
+            float4 q3 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
+            if (two) { q3 = q[3]; q4 = q[4]; }
+            const f3 o = mk3(s.oxy.x, s.oxy.y, s.ozix.x);
+            if (intersect_tri(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), o, s.rd, s.t))
+                s.hit = __float_as_int(q2.y);
+            if (two && intersect_tri(mk3(q2.w, q3.x, q3.y), mk3(q3.z, q3.w, q4.x), mk3(q4.y, q4.z, q4.w), o, s.rd, s.t))
+                s.hit = __float_as_int(q2.z);
+            if (left <= 2) trav_pop(p, s, stack, stride, spill);
+            else s.cur = ~(packed + 64 - 2);                  // next pair, two fewer left
         }
         if (hpt_ballot(s.cur < 0) == 0ull) break;
     }
