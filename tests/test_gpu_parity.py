@@ -214,6 +214,33 @@ def test_single_leaf_tree_and_empty_tree():
     assert mismatch(be0.kernel_execute(0), o0.kernel_execute(0)[0]) == 0
 
 
+@pytest.mark.parametrize("n", [1, 2, 5, 32, 63, 64])
+def test_big_and_tiny_leaves_either_upload_order(n):
+    """Leaves of 1..64 triangles (the traversal reads them as records of two; the upload accepts up to 64 per
+    leaf) as a one-leaf tree, triangles uploaded before the tree and the tree replaced afterwards."""
+    from oracle import binding as orc
+    s, bvh, _ = get_scene("random", n=2000, seed=1, width=40, height=40)
+    tris = bvh["triangles"][:n].copy()
+    v = np.concatenate([tris["v1"][:, :3], tris["v1"][:, :3] + tris["e1"][:, :3], tris["v1"][:, :3] + tris["e2"][:, :3]])
+    bbox = np.zeros(1, api.BBOX); bbox["min"][0] = v.min(0); bbox["max"][0] = v.max(0)
+    info = np.zeros(1, api.INFO); info["nPrimitives"][0] = n
+    o = orc.OracleScene(tris, bbox, info, s["primitives"], s["materials"], s["camera"], 40, 40, s["cfg"])
+    be = api.Backend(40, 40)
+    be.upload_triangles(tris); be.upload_bvh(bbox, info)            # triangles first
+    be.set_scene(s["primitives"], s["materials"]); be.set_camera(s["camera"]); be.set_config(s["cfg"])
+    assert mismatch(be.kernel_execute(0), o.kernel_execute(0)[0]) == 0
+    be.upload_bvh(bvh["bbox"], bvh["info"]); be.upload_triangles(bvh["triangles"])      # then the full scene replaces it
+    _, _, ofull = get_scene("random", n=2000, seed=1, width=40, height=40)
+    assert mismatch(be.kernel_execute(0), ofull.kernel_execute(0)[0]) == 0
+    hit, t = be.primary_hits(3)
+    oh, ot, _ = ofull.primary_hits(3)
+    assert np.array_equal(hit, oh) and mismatch(t, ot) == 0
+    if n == 64:
+        info["nPrimitives"][0] = 65
+        with pytest.raises(api.HptError, match="limit"):
+            be.upload_bvh(bbox, info)
+
+
 def test_error_reporting():
     s, bvh, _ = get_scene("cornell", width=32, height=32)
     be = api.Backend(32, 32)
