@@ -89,6 +89,22 @@ def test_obj_reader_parallel_chunks(tmp_path, monkeypatch):
         api.load_obj(str(q))
 
 
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_host_code_under_sanitizers(tmp_path, san):
+    """The two multi-threaded pieces of the host side (BVH builder: shared top levels + subtree tasks; OBJ
+    reader: three passes over chunks) run clean under ThreadSanitizer and under ASan + UBSan."""
+    import subprocess
+    host = os.path.join(ROOT, "pathtracer_amd", "csrc", "host")
+    exe = tmp_path / "san"
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + host, os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), os.path.join(host, "bvh.cpp"),
+                        os.path.join(host, "obj_reader.cpp"), "-o", str(exe), "-pthread"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, HPT_BUILD_THREADS="6", HPT_BUILD_TASK_SIZE="500")
+    r = subprocess.run([str(exe), "40000", str(tmp_path / "s.obj")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-3000:]
+
+
 def test_host_bvh_rejects_small_input():
     with pytest.raises(api.HptError):
         api.build_bvh(np.zeros((11, 3, 3), np.float32))
