@@ -58,6 +58,8 @@ struct hpt_ctx {
     int root_ref_tris = HPT_REF_DONE;
     float4 *d_pairs = nullptr;
     bool pairs_dirty = true;
+    bool singles = false;            // record form of the current tree: one triangle per 48-B record (ensure_pairs)
+    int leaf_records = 0;            // HPT_LEAF_RECORDS: 0 = per tree, 1 = singles, 2 = pairs
     hpt_primitive *d_prims = nullptr;
     int n_prims = 0;
     hpt_material *d_mats = nullptr;
@@ -144,24 +146,32 @@ int n_tiles(const hpt_ctx *c) { return tiles_x(c) * tiles_y(c); }
 // tiles of the largest shard: every rank's slab has this many (all-gather wants equal sizes)
 int slab_tiles(const hpt_ctx *c) { return (n_tiles(c) + c->world - 1) / c->world; }
 
-// Builds the traversal's triangle records (two consecutive triangles of a leaf per 80 B, render_kernels.h) and
-// uploads the nodes with their leaf references re-pointed at them.  Leaves are numbered in node order, so a
-// near-first descent walks the records forward.
+// Builds the traversal's triangle records (render_kernels.h) and uploads the nodes with their leaf references
+// re-pointed at them.  Leaves are numbered in node order, so a near-first descent walks the records forward.
+// Record form, per tree: two consecutive triangles of a leaf per 80 B, or -- when the leaves hold fewer than
+// 1.25 triangles on average (HPT_LEAF_RECORDS=pairs|singles overrides) -- one triangle per 48 B.
 int ensure_pairs(hpt_ctx *ctx) {
     if (!ctx->pairs_dirty) return HPT_OK;
     if (ctx->root_ref_tris == HPT_REF_DONE) { ctx->pairs_dirty = false; return HPT_OK; }     // no tree
     if (ctx->max_leaf_end > ctx->n_tris) return HPT_OK;       // fill_params reports it
     std::vector<WideNode> wide(ctx->h_wide);
+    size_t n_leaves = ctx->root_ref_tris < 0 ? 1 : 0, leaf_tris = ctx->root_ref_tris < 0 ? (size_t)((~ctx->root_ref_tris & 63) + 1) : 0;
+    for (const WideNode &w : wide)
+        for (int32_t ref : {w.ref0, w.ref1})
+            if (ref < 0) { n_leaves++; leaf_tris += (size_t)((~ref & 63) + 1); }
+    bool singles = leaf_tris * 4 < n_leaves * 5;
+    if (ctx->leaf_records > 0) singles = ctx->leaf_records == 1;
+    const int rec_floats = singles ? 4 * HPT_SINGLE_FLOAT4S : 4 * HPT_PAIR_FLOAT4S;
     std::vector<float> rec;
-    rec.reserve(((size_t)ctx->n_tris / 2 + wide.size() + 1) * 20);
+    rec.reserve(singles ? leaf_tris * 12 : ((size_t)ctx->n_tris / 2 + wide.size() + 1) * 20);
     auto repoint = [&](int32_t &ref) {
         if (ref >= 0) return;
         const int packed = ~ref, first = packed >> 6, n = (packed & 63) + 1;
-        const int first_pair = (int)(rec.size() / 20);
-        for (int i = 0; i < n; i += 2) {
+        const int first_rec = (int)(rec.size() / (size_t)rec_floats);
+        for (int i = 0; i < n; i += singles ? 1 : 2) {
             float r[20];
             for (int k = 0; k < 20; k++) r[k] = 0.0f;
-            for (int h = 0; h < 2 && i + h < n; h++) {
+            for (int h = 0; h < (singles ? 1 : 2) && i + h < n; h++) {
                 const hpt_triangle &t = ctx->h_tris[first + i + h];
                 float *f = r + (h ? 11 : 0);
                 f[0] = t.v1.x; f[1] = t.v1.y; f[2] = t.v1.z; f[3] = t.e1.x; f[4] = t.e1.y; f[5] = t.e1.z;
@@ -169,18 +179,20 @@ int ensure_pairs(hpt_ctx *ctx) {
                 const int32_t id = first + i + h;
                 memcpy(r + 9 + h, &id, 4);
             }
-            rec.insert(rec.end(), r, r + 20);
+            rec.insert(rec.end(), r, r + rec_floats);
         }
-        ref = HPT_PAIR_REF(first_pair, n);
+        ref = HPT_PAIR_REF(first_rec, n);
     };
     int32_t root = ctx->root_ref_tris;
     repoint(root);
     for (WideNode &w : wide) { repoint(w.ref0); repoint(w.ref1); }
-    if (rec.size() / 20 >= (size_t)(1 << 25)) return fail(ctx, HPT_ERR_BVH, "too many triangle records");
+    if (rec.size() / (size_t)rec_floats >= (size_t)(1 << 25)) return fail(ctx, HPT_ERR_BVH, "too many triangle records");
+    rec.resize(rec.size() + 8, 0.0f);
     int rc = replace_buffer(ctx, ctx->d_nodes, wide.data(), wide.size() * sizeof(WideNode));
     if (rc) return rc;
     if ((rc = replace_buffer(ctx, ctx->d_pairs, rec.data(), rec.size() * sizeof(float)))) return rc;
     ctx->root_ref = root;
+    ctx->singles = singles;
     ctx->pairs_dirty = false;
     return HPT_OK;
 }
@@ -197,6 +209,7 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     if (rc_pairs) return rc_pairs;
     memset(&p, 0, sizeof p);
     p.pairs = ctx->d_pairs;
+    p.singles = ctx->singles ? 1 : 0;
     p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.mats = ctx->d_mats;
     p.image = d_image; p.hit_id = ctx->d_hit_id; p.hit_t = ctx->d_hit_t;
     p.work_counter = ctx->d_work; p.counters = ctx->d_counters;
@@ -281,7 +294,8 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     p.samples = ctx->d_samples;
 
     size_t lds; long blocks_max;
-    if ((rc = prepare_persistent(ctx, (const void *)render_kernel, p, lds, blocks_max))) return rc;
+    const void *kernel = ctx->singles ? (const void *)render_kernel<true> : (const void *)render_kernel<false>;
+    if ((rc = prepare_persistent(ctx, kernel, p, lds, blocks_max))) return rc;
 
     const bool single = total <= batch_alloc;     // then the events bracket render_kernel alone
     if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -296,7 +310,8 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
         p.spill_stride = (uint32_t)(blocks * kBlock);
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
         if (single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        hipLaunchKernelGGL(render_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
+        if (ctx->singles) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
+        else hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
         HIP_TRY(ctx, hipGetLastError());
         if (single) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         hipLaunchKernelGGL(fold_kernel, dim3((p.n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, p);
@@ -338,6 +353,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     ctx->n_cu = prop.multiProcessorCount;
     if (const char *e = getenv("HPT_SHADE_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_threshold = v; }
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
+    if (const char *e = getenv("HPT_LEAF_RECORDS")) ctx->leaf_records = !strcmp(e, "singles") ? 1 : !strcmp(e, "pairs") ? 2 : 0;
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
     if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->fetch_chunk = v; }
@@ -553,14 +569,15 @@ static int iter_launch_params(hpt_ctx *ctx, RenderParams &p, unsigned &blocks) {
 // traversal half of a call: persistent iter_trace_kernel over this shard's pixel slots
 static int iter_trace(hpt_ctx *ctx, RenderParams &p, int first) {
     size_t lds; long blocks_max;
-    int rc = prepare_persistent(ctx, (const void *)iter_trace_kernel, p, lds, blocks_max);
+    int rc = prepare_persistent(ctx, ctx->singles ? (const void *)iter_trace_kernel<true> : (const void *)iter_trace_kernel<false>, p, lds, blocks_max);
     if (rc) return rc;
     long blocks = blocks_max;
     long need = ((long)p.n_slots + kBlock - 1) / kBlock;
     if (blocks > need) blocks = need;
     p.spill_stride = (uint32_t)(blocks * kBlock);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(iter_trace_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
+    if (ctx->singles) hipLaunchKernelGGL(iter_trace_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
+    else hipLaunchKernelGGL(iter_trace_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
     HIP_TRY(ctx, hipGetLastError());
     return HPT_OK;
 }

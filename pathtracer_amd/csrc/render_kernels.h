@@ -35,7 +35,8 @@ static_assert(sizeof(WideNode) == 64, "WideNode must be one 64-B line");
 struct RenderParams {
     const WideNode *nodes;
     const float4 *tris;              // hpt_triangle[] viewed as 3 x float4 (shading: normal of the hit triangle)
-    const float4 *pairs;             // triangles as the traversal reads them: 80-B records of two (leaf references point here)
+    const float4 *pairs;             // triangles as the traversal reads them: 80-B records of two, or 48-B records of one
+                                     // (singles != 0); leaf references point here
     const hpt_primitive *prims;
     const hpt_material *mats;
     float *image;                    // width*height*3
@@ -67,6 +68,7 @@ struct RenderParams {
     int32_t batch;                   // iterations in this launch: spp_base .. spp_base + batch - 1
     int32_t spp_base;
     int32_t fetch_chunk;             // work items a wave reserves per atomic, <= 4096 (scheduling only)
+    int32_t singles;                 // record form of this tree (chosen per tree by the host, see HPT_SINGLE_*)
     int32_t fetch_threshold;         // iter_trace_kernel: lanes that must want a new ray before the wave fetches (scheduling only)
 };
 
@@ -233,9 +235,14 @@ __device__ __forceinline__ bool intersect_tri(f3 v1, f3 edge1, f3 edge2, f3 o, f
 // never read.  Float slots: a = 0..8, id_a = 9, id_b = 10, b = 11..19.
 #define HPT_PAIR_FLOAT4S 5
 #define HPT_PAIR_REF(first_pair, n) (~(((first_pair) << 6) | ((n) - 1)))
-__device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ pairs, int pair, int half, f3 o, f3 d, float &t, int &id) {
-    const float *f = reinterpret_cast<const float *>(pairs + (size_t)HPT_PAIR_FLOAT4S * pair) + (half ? 11 : 0);
-    id = __float_as_int(reinterpret_cast<const float *>(pairs + (size_t)HPT_PAIR_FLOAT4S * pair)[9 + half]);
+// The other record form, for trees whose leaves hold (almost) one triangle each: one triangle per 48-B record,
+// the first half of a pair record on its own (a = 0..8, id = 9).  There the second-half test would serve a lane
+// or two per step, and a traversal kernel compiled without it runs 25 % faster on such a tree (C4, 10 M
+// triangles: profiles/r01_tuning.md), so the host picks the form per tree and the kernels exist in both.
+#define HPT_SINGLE_FLOAT4S 3
+__device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ rec, int half, f3 o, f3 d, float &t, int &id) {
+    const float *f = reinterpret_cast<const float *>(rec) + (half ? 11 : 0);
+    id = __float_as_int(reinterpret_cast<const float *>(rec)[9 + half]);
     return intersect_tri(mk3(f[0], f[1], f[2]), mk3(f[3], f[4], f[5]), mk3(f[6], f[7], f[8]), o, d, t);
 }
 
@@ -318,7 +325,9 @@ __device__ __forceinline__ int traverse(const RenderParams &p, f3 o, f3 d, float
             int first = packed >> 6, n = (packed & 63) + 1;     // first PAIR of the leaf, triangles in it
             for (int i = 0; i < n; i++) {
                 int id;
-                if (intersect_pair_half(p.pairs, first + (i >> 1), i & 1, o, d, t, id)) hit = id;
+                const float4 *rec = p.singles ? p.pairs + (size_t)HPT_SINGLE_FLOAT4S * (first + i)
+                                              : p.pairs + (size_t)HPT_PAIR_FLOAT4S * (first + (i >> 1));
+                if (intersect_pair_half(rec, p.singles ? 0 : (i & 1), o, d, t, id)) hit = id;
             }
             pop = true;
         }
@@ -506,7 +515,25 @@ __device__ __forceinline__ void trav_pop(const RenderParams &p, Trav &s, uint2 *
 // TRI step: up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a
 // leaf), two per iteration from one pair record.  A lane is in the TRI state exactly when cur < 0, so the state
 // is re-read from cur, not carried.  ~cur = (next pair << 6) | (triangles left - 1).
+template <bool SINGLES>
 __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
+    if (SINGLES) {
+        // one triangle per 48-B record: ~cur = (next record << 6) | (triangles left - 1)
+        for (int k = 0; k < p.tris_per_trip; k++) {
+            if (s.cur < 0) {
+                const int packed = ~s.cur, rec = packed >> 6;
+                const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.pairs) + (unsigned)rec * 48u);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                if (intersect_tri(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x),
+                                  mk3(s.oxy.x, s.oxy.y, s.ozix.x), s.rd, s.t))
+                    s.hit = __float_as_int(q2.y);
+                if ((packed & 63) == 0) trav_pop(p, s, stack, stride, spill);
+                else s.cur = ~(packed + 63);                      // next record, one fewer left
+            }
+            if (hpt_ballot(s.cur < 0) == 0ull) break;
+        }
+        return;
+    }
     for (int k = 0; k < p.tris_per_trip; k += 2) {
         if (s.cur < 0) {
             const int packed = ~s.cur, pair = packed >> 6, left = (packed & 63) + 1;
@@ -603,6 +630,7 @@ __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o,
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 6
 #endif
+template <bool SINGLES>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
@@ -697,7 +725,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                 }
             }
         } else if (nT > nN) {
-            trav_tri_steps(p, tv, stack, stride, spill);
+            trav_tri_steps<SINGLES>(p, tv, stack, stride, spill);
         } else {
             trav_node_steps(p, tv, stack, stride, spill);
         }
@@ -767,6 +795,7 @@ struct IterState {
 // steps of render_kernel and stores (hit, t).  first != 0: the ray is the camera ray of jitter cell 0, which
 // is generated here and left in cur_a/cur_b (origin, direction) and cur_d.x (rng counter after the jitter).
 // Pixels whose cached bounce already ended the path trace nothing.
+template <bool SINGLES>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const RenderParams p, const IterState it, int first) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
@@ -829,7 +858,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const Re
                 trav_start(p, tv, o, d);
             }
         } else if (nT > nN) {
-            trav_tri_steps(p, tv, stack, stride, spill);
+            trav_tri_steps<SINGLES>(p, tv, stack, stride, spill);
         } else {
             trav_node_steps(p, tv, stack, stride, spill);
         }

@@ -136,6 +136,30 @@ def test_scheduling_knobs_do_not_change_results(env, monkeypatch):
         assert mismatch(d.cpu().numpy(), o.render(0, 3)[0]) == 0
 
 
+@pytest.mark.parametrize("form", ["singles", "pairs"])
+def test_leaf_record_forms_do_not_change_results(form, monkeypatch):
+    """The triangle-record form (one or two triangles per record) is a per-tree layout choice of the backend,
+    with its own instantiation of the traversal kernels: whole-path render, primary hits and the iterative
+    pipeline stay bit-exact in either."""
+    monkeypatch.setenv("HPT_LEAF_RECORDS", form)
+    for name, kw in [("sponza", dict(width=96, height=54)), ("random", dict(n=2000, seed=1, width=64, height=64))]:
+        s, bvh, o = get_scene(name, **kw)
+        be = backend_for(s, bvh)
+        d = dev_image(be)
+        be.render(0, 3, d.data_ptr()); be.synchronize()
+        assert mismatch(d.cpu().numpy(), o.render(0, 3)[0]) == 0
+        hit, t = be.primary_hits(1)
+        oh, ot, _ = o.primary_hits(1)
+        assert np.array_equal(hit, oh) and mismatch(t, ot) == 0
+        want = np.zeros((s["width"] * s["height"], 3), np.float32)
+        d.zero_()
+        be.first_bounce(); o.iter_first_bounce()
+        for _ in range(4):
+            be.bounce(); be.reconstruct_paths(d.data_ptr()); o.iter_bounce(); o.iter_reconstruct(want)
+        be.synchronize()
+        assert mismatch(d.cpu().numpy(), want) == 0
+
+
 def test_sample_buffer_batches(monkeypatch):
     """A render whose samples do not fit the sample buffer is split into several launches of render_kernel,
     each folded in iteration order: same image.  1 MB holds 10 iterations of a 96x96 shard."""
@@ -214,11 +238,15 @@ def test_single_leaf_tree_and_empty_tree():
     assert mismatch(be0.kernel_execute(0), o0.kernel_execute(0)[0]) == 0
 
 
+@pytest.mark.parametrize("form", ["singles", "pairs", None])
 @pytest.mark.parametrize("n", [1, 2, 5, 32, 63, 64])
-def test_big_and_tiny_leaves_either_upload_order(n):
-    """Leaves of 1..64 triangles (the traversal reads them as records of two; the upload accepts up to 64 per
-    leaf) as a one-leaf tree, triangles uploaded before the tree and the tree replaced afterwards."""
+def test_big_and_tiny_leaves_either_upload_order(n, form, monkeypatch):
+    """Leaves of 1..64 triangles (the traversal reads them as records of two, or of one when the tree's leaves
+    are small: both forms forced, and the per-tree choice; the upload accepts up to 64 per leaf) as a one-leaf
+    tree, triangles uploaded before the tree and the tree replaced afterwards."""
     from oracle import binding as orc
+    if form:
+        monkeypatch.setenv("HPT_LEAF_RECORDS", form)
     s, bvh, _ = get_scene("random", n=2000, seed=1, width=40, height=40)
     tris = bvh["triangles"][:n].copy()
     v = np.concatenate([tris["v1"][:, :3], tris["v1"][:, :3] + tris["e1"][:, :3], tris["v1"][:, :3] + tris["e2"][:, :3]])
