@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--scene", default="sponza", help="sponza (C3, headline) | bunny (C2) | cornell (C1) | glossy (C5) | tenm (C4)")
     ap.add_argument("--spp", type=int, default=0, help="override the config's spp (debugging only: makes the number non-headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "samples"],
+                    help="N>1: tiles = 8x8 tiles round-robin + one all-gather (bit-identical image, the default); "
+                         "samples = iterations s %% N == rank + one all-reduce (SURVEY.md 8e secondary mode)")
     args = ap.parse_args()
 
     import torch
@@ -104,14 +107,25 @@ def main():
     t_build = time.perf_counter() - t_build
     be = api.Backend(w, h, device=local_rank)
     be.load(scn, bvh)
-    be.set_shard(rank, world)
+    if args.shard == "tiles":
+        be.set_shard(rank, world)
+    else:
+        be.set_sample_shard(rank, world)
     be.set_stream(torch.cuda.current_stream().cuda_stream)
     image = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
 
     def step():
         be.render(0, spp, image.data_ptr())
-        if world > 1:
+        if world > 1 and args.shard == "tiles":
             pdist.gather_image(be, image, world)
+        elif world > 1:
+            be.synchronize()
+            if dist_backend == "nccl":
+                pdist.reduce_samples(image, pdist.sample_shard_count(0, spp, rank, world), spp)
+            else:                                         # gloo rehearsal: stage through the host
+                host = image.cpu()
+                pdist.reduce_samples(host, pdist.sample_shard_count(0, spp, rank, world), spp)
+                image.copy_(host)
 
     def fence():
         be.synchronize()
@@ -191,7 +205,8 @@ def main():
                        "width": w, "height": h, "spp": spp, "max_depth": scn["cfg"]["max_depth"],
                        "triangles": int(len(bvh["triangles"])), "bvh_nodes": int(len(bvh["bbox"])),
                        "rays_per_frame": rays_frame, "primary_rays": rays_p, "bounce_rays": rays_b,
-                       "sharding": "8x8 tiles round-robin over %d rank(s), all-gather of slabs" % world,
+                       "sharding": ("8x8 tiles round-robin over %d rank(s), all-gather of slabs" if args.shard == "tiles" else
+                                    "iterations s %% %d == rank, all-reduce of weighted running means") % world,
                        "bvh_build_s": t_build},
             "roofline": roofline,
         }

@@ -50,6 +50,15 @@ int hpt_set_stream(hpt_ctx *ctx, void *hip_stream);
  * tiles t with t % world == r.  Default (0,1) = whole image. */
 int hpt_set_shard(hpt_ctx *ctx, int rank, int world);
 
+/* Sample-range shard of this context (the secondary mode, for progressive rendering of one
+ * image by several GPUs): rank r of `world` renders the iterations s with s % world == r of every pixel it
+ * owns, and hpt_render's image is the running mean over ITS samples (pathtracer.cpp:200-217 with its own
+ * count).  Possible because the random stream is keyed by (pixel, iteration), not sequential per pixel as in
+ * the reference (ray_kernel.cl:259-266).  The frame is sum_r (n_r / N) * image_r, one all-reduce; the fp32
+ * summation order differs from the unsharded mean, so that sum is within 1e-5 relative of it, not
+ * bit-identical (each rank's image is).  Default (0,1).  No counterpart in the reference. */
+int hpt_set_sample_shard(hpt_ctx *ctx, int rank, int world);
+
 /* Replaces OpenCL_Manager::triangles_to_texture (opencl_manager.hpp:21,
  * opencl_manager.cpp:207-221).  Copies at call time. Triangles are in BVH leaf order. */
 int hpt_upload_triangles(hpt_ctx *ctx, const hpt_triangle *triangles, int n_triangles);

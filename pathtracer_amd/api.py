@@ -18,7 +18,7 @@ _LIB = None
 
 # every symbol include/hpt/hpt.h declares
 C_ABI_SYMBOLS = [
-    "hpt_create", "hpt_destroy", "hpt_last_error", "hpt_set_stream", "hpt_set_shard", "hpt_upload_triangles",
+    "hpt_create", "hpt_destroy", "hpt_last_error", "hpt_set_stream", "hpt_set_shard", "hpt_set_sample_shard", "hpt_upload_triangles",
     "hpt_upload_bvh", "hpt_set_scene", "hpt_set_camera", "hpt_set_config", "hpt_get_config", "hpt_kernel_execute",
     "hpt_reconstruct", "hpt_render_sample", "hpt_render", "hpt_primary_hits", "hpt_slab_floats", "hpt_pack_tiles",
     "hpt_unpack_tiles", "hpt_tonemap", "hpt_synchronize", "hpt_get_stats",
@@ -48,6 +48,7 @@ def lib():
         L.hpt_last_error.argtypes = [vp]; L.hpt_last_error.restype = C.c_char_p
         L.hpt_set_stream.argtypes = [vp, vp]
         L.hpt_set_shard.argtypes = [vp, i32, i32]
+        L.hpt_set_sample_shard.argtypes = [vp, i32, i32]
         L.hpt_upload_triangles.argtypes = [vp, vp, i32]
         L.hpt_upload_bvh.argtypes = [vp, vp, vp, i32]
         L.hpt_set_scene.argtypes = [vp, vp, i32, vp, i32]
@@ -158,6 +159,10 @@ class Backend:
 
     def set_shard(self, rank, world):
         self._chk(self.L.hpt_set_shard(self.h, rank, world))
+
+    def set_sample_shard(self, rank, world):
+        """Rank r of world renders the iterations s % world == r (dist.reduce_samples combines the images)."""
+        self._chk(self.L.hpt_set_sample_shard(self.h, rank, world))
 
     def upload_triangles(self, tris):
         tris = np.ascontiguousarray(tris, TRIANGLE)

@@ -38,6 +38,7 @@ struct hpt_ctx {
     int width = 0, height = 0;
     hipStream_t stream = nullptr;
     int rank = 0, world = 1;
+    int sample_rank = 0, sample_world = 1;   // hpt_set_sample_shard: this context renders iterations s % sample_world == sample_rank
     hpt_config cfg{15, 3, 2.0f, 0x5EEDu};
     hpt_camera cam{};
     bool have_camera = false;
@@ -226,7 +227,7 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     if (local_tiles < 0) local_tiles = 0;
     p.n_slots = (uint32_t)local_tiles * 64u;
     p.n_work = p.n_slots;
-    p.batch = 1; p.spp_base = spp_begin;
+    p.batch = 1; p.spp_base = spp_begin; p.spp_first = spp_begin; p.spp_stride = 1;
     p.raw_sample = raw;
     p.shade_threshold = ctx->shade_threshold;
     p.tris_per_trip = ctx->tris_per_trip;
@@ -283,7 +284,13 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     const long idx_max = (long)(0xF0000000u / p.n_slots);
     if (batch_max > idx_max) batch_max = idx_max;
     if (batch_max < 1) batch_max = 1;
-    const int total = spp_end - spp_begin;
+    // sample shards: this rank renders the iterations s = sample_rank + sample_world * l of the range, and folds
+    // them as ITS running mean (count l + 1); hpt_kernel_execute (raw) names its iteration itself
+    const int G = raw ? 1 : ctx->sample_world, r = raw ? 0 : ctx->sample_rank;
+    auto locals_below = [&](int s) { return s <= r ? 0 : (s - r + G - 1) / G; };      // # of l with r + G*l < s
+    const int l_begin = locals_below(spp_begin), l_end = locals_below(spp_end);
+    const int total = l_end - l_begin;
+    if (total <= 0) return HPT_OK;
     const int batch_alloc = total < batch_max ? total : (int)batch_max;
     const size_t samples_need = bytes_per_iteration * (size_t)batch_alloc;
     if (samples_need > ctx->samples_bytes) {
@@ -299,9 +306,10 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
 
     const bool single = total <= batch_alloc;     // then the events bracket render_kernel alone
     if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int base = spp_begin; base < spp_end; base += batch_alloc) {
+    for (int base = l_begin; base < l_end; base += batch_alloc) {
         p.spp_base = base;
-        p.batch = (spp_end - base) < batch_alloc ? (spp_end - base) : batch_alloc;
+        p.spp_first = r + G * base; p.spp_stride = G;
+        p.batch = (l_end - base) < batch_alloc ? (l_end - base) : batch_alloc;
         p.n_work = p.n_slots * (uint32_t)p.batch;
         long blocks = blocks_max;
         long need = ((long)p.n_work + kBlock - 1) / kBlock;
@@ -397,6 +405,13 @@ int hpt_set_shard(hpt_ctx *ctx, int rank, int world) {
     if (!ctx) return HPT_ERR_INVALID;
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, HPT_ERR_INVALID, "bad shard %d of %d", rank, world);
     ctx->rank = rank; ctx->world = world;
+    return HPT_OK;
+}
+
+int hpt_set_sample_shard(hpt_ctx *ctx, int rank, int world) {
+    if (!ctx) return HPT_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, HPT_ERR_INVALID, "bad sample shard %d of %d", rank, world);
+    ctx->sample_rank = rank; ctx->sample_world = world;
     return HPT_OK;
 }
 

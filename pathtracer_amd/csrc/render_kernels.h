@@ -65,8 +65,9 @@ struct RenderParams {
     uint32_t spill_stride;           // lanes in the grid
     float *samples;                  // [batch sample][slot][3]: one radiance sample per (pixel, iteration) of this launch
     uint32_t n_slots;                // pixel slots of this shard = local tiles * 64
-    int32_t batch;                   // iterations in this launch: spp_base .. spp_base + batch - 1
-    int32_t spp_base;
+    int32_t batch;                   // samples per pixel in this launch: the rank's samples spp_base .. spp_base + batch - 1
+    int32_t spp_base;                // (fold_kernel's running-mean count), which are the frame's iterations
+    int32_t spp_first, spp_stride;   // spp_first + k * spp_stride (sample shards: stride = ranks; otherwise 1)
     int32_t fetch_chunk;             // work items a wave reserves per atomic, <= 4096 (scheduling only)
     int32_t singles;                 // record form of this tree (chosen per tree by the host, see HPT_SINGLE_*)
     int32_t fetch_threshold;         // iter_trace_kernel: lanes that must want a new ray before the wave fetches (scheduling only)
@@ -644,7 +645,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // work items this WAVE has reserved from the work counter (wave-uniform)
     bool exhausted = false;                  // the work counter has passed n_work (wave-uniform)
-    unsigned out_idx = 0;                // sample slot of the current path: (s - spp_base) * n_slots + pixel slot
+    unsigned out_idx = 0;                // sample slot of the current path: (sample of the launch) * n_slots + pixel slot
     uint32_t key = 0, ctr = 0;
     f3 color = mk3(0, 0, 0), weight = mk3(1, 1, 1);
     Trav tv;
@@ -708,7 +709,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
                         const unsigned slot = tile * 64u + (work & 63u);
                         gid = work_to_pixel(p, slot);
-                        if (gid >= 0) { s = p.spp_base + (int)sl; out_idx = sl * p.n_slots + slot; want = false; }
+                        if (gid >= 0) { s = p.spp_first + (int)sl * p.spp_stride; out_idx = sl * p.n_slots + slot; want = false; }
                     }
                     const unsigned cnt = (unsigned)__popcll(need);
                     chunk_next += cnt < avail ? cnt : avail;

@@ -86,3 +86,23 @@ def gather_image_cpu(slab, world, group=None):
     out = [torch.empty_like(slab) for _ in range(world)]
     dist.all_gather(out, slab, group=group)
     return torch.cat(out)
+
+
+# ---- sample-range shards (secondary mode): rank r renders the iterations s % world == r ----
+
+def sample_shard_count(spp_begin, spp_end, rank, world):
+    """Iterations of [spp_begin, spp_end) that rank `rank` of `world` renders (hpt_set_sample_shard)."""
+    below = lambda s: 0 if s <= rank else (s - rank + world - 1) // world
+    return below(spp_end) - below(spp_begin)
+
+
+def reduce_samples(image, n_local, n_total, group=None):
+    """Combines the per-rank running means of a sample-sharded render into the frame's mean, in place on every
+    rank: image <- sum_r (n_r / N) * image_r, ONE all-reduce (RCCL when the group's backend is "nccl", gloo on
+    CPU tensors in the tests).  `image` is this rank's mean over its n_local samples (a torch tensor, device or
+    CPU); the backend's stream must have been synchronised.  fp32 sum in rank order of the collective: within
+    1e-5 relative of the unsharded running mean, not bit-identical to it."""
+    import torch.distributed as dist
+    image.mul_(float(n_local) / float(n_total))
+    dist.all_reduce(image, op=dist.ReduceOp.SUM, group=group)
+    return image

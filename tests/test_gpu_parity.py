@@ -203,6 +203,45 @@ def test_tile_shards_reassemble_bit_exact(w, h, world):
     assert mismatch(out.cpu().numpy(), full) == 0
 
 
+@pytest.mark.parametrize("world,budget", [(2, None), (3, "1")])
+def test_sample_shards(world, budget, monkeypatch):
+    """hpt_set_sample_shard: rank r renders the iterations s % world == r and folds them as its own running
+    mean.  Each rank's image is bit-exact against the oracle's samples of those iterations folded the same
+    way (also when the render is continued, and when it is cut into batches: 1 MB holds 10 iterations here);
+    the (n_r/N)-weighted sum is the unsharded frame within 1e-5 relative (fp32 summation order differs)."""
+    from pathtracer_amd import dist as pd
+    if budget:
+        monkeypatch.setenv("HPT_SAMPLE_BUDGET_MB", budget)
+    s, bvh, o = get_scene("cornell", width=96, height=96)
+    n_total, cut = 37, 5
+    samples = [o.kernel_execute(k)[0].reshape(-1) for k in range(n_total)]
+    be = backend_for(s, bvh)
+    frame = np.zeros(96 * 96 * 3, np.float32)
+    for r in range(world):
+        be.set_sample_shard(r, world)
+        d = dev_image(be)
+        be.render(0, cut, d.data_ptr())                   # continued render: [0, cut) then [cut, n_total)
+        be.render(cut, n_total, d.data_ptr()); be.synchronize()
+        mine = samples[r::world]
+        mean = mine[0].copy()
+        for k in range(1, len(mine)):
+            it = np.float32(k + 1)
+            mean = (np.float32(1) / it) * mine[k] + (np.float32(k) / it) * mean
+        assert mismatch(d.cpu().numpy(), mean) == 0, r
+        assert pd.sample_shard_count(0, n_total, r, world) == len(mine)
+        assert be.stats()["paths"] == pd.sample_shard_count(cut, n_total, r, world) * 96 * 96
+        frame += np.float32(len(mine) / n_total) * d.cpu().numpy()
+    want = o.render(0, n_total)[0].reshape(-1)
+    assert np.allclose(frame, want, rtol=1e-5, atol=1e-6)
+    be.set_sample_shard(0, 1)
+    d = dev_image(be)
+    be.render(0, n_total, d.data_ptr()); be.synchronize()
+    assert mismatch(d.cpu().numpy(), want) == 0          # back to the whole range: bit-exact again
+    assert mismatch(be.kernel_execute(4), samples[4]) == 0
+    with pytest.raises(api.HptError, match="sample shard"):
+        be.set_sample_shard(2, 2)
+
+
 def test_tonemap_kernel():
     from oracle import binding as orc
     s, bvh, o = get_scene("cornell", width=64, height=64)
