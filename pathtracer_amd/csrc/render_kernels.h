@@ -561,9 +561,14 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
     for (;;) {
         if ((unsigned)s.cur < (unsigned)HPT_REF_IDLE) {
             // 32-bit byte offset (n_wide < 2^25): saddr + voffset addressing, no 64-bit address math
-            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + ((unsigned)s.cur << 6));
+            const unsigned node_off = (unsigned)s.cur << 6;
+            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + node_off);
             const float4 X = q[0], Y = q[1], Z = q[2];
             const int4 m = *reinterpret_cast<const int4 *>(q + 3);
+            // Keeps the offset register alive past the four loads, so none of them is given it as (part of) its
+            // destination: whenever hipcc let the last load overwrite its own address register the kernel ran
+            // 20-25 % slower on the HBM-bound C4 with identical instruction and traffic counts (profiles/r01_tuning.md).
+            asm volatile("" : : "v"(node_off), "v"(m.w));
             const bool nx = s.flags & 1u, ny = s.flags & 2u, nz = s.flags & 4u;
             float t0, t1;
             unsigned long long M0, M1;                    // lanes whose child 0 / child 1 is hit with tmin < t
@@ -635,13 +640,13 @@ template <bool SINGLES>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
-    unsigned n_primary = 0, n_bounce = 0, n_paths = 0;
+    unsigned n_primary = 0, n_bounce = 0, n_paths = 0;   // per WAVE (from ballots: scalar registers, not three per lane)
 #ifdef HPT_PROFILE_STEPS
     unsigned long long prof_it[3] = {0, 0, 0}, prof_act[3] = {0, 0, 0};
     unsigned long long prof_waitS = 0, prof_idle = 0;     // per lane: trips spent waiting for SHADE / without work
 #endif
 
-    int gid = -1, s = 0, b = -1;         // b == -1: the lane needs a new path
+    int b = -1;                          // b == -1: the lane needs a new path
     const unsigned lane = threadIdx.x & 63u;
     unsigned chunk_next = 0, chunk_end = 0;  // work items this WAVE has reserved from the work counter (wave-uniform)
     bool exhausted = false;                  // the work counter has passed n_work (wave-uniform)
@@ -672,15 +677,18 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
         if (nS >= p.shade_threshold || nN + nT == 0) {
             {
                 Ray r;
+                int gid = -1, s = 0;     // pixel and iteration of a path fetched in this step (only its key and camera ray need them)
+                bool ended = false;
+                n_primary += (unsigned)__popcll(hpt_ballot(wantS && b == 0));
+                n_bounce += (unsigned)__popcll(hpt_ballot(wantS && b > 0));
                 if (wantS && b >= 0) {   // a ray has just finished: one bounce of the path loop
-                    if (b == 0) n_primary++; else n_bounce++;
                     r.o = mk3(tv.oxy.x, tv.oxy.y, tv.ozix.x); r.d = tv.rd;
                     bool go_on = shade_bounce(p, tv.hit, tv.t, r, key, ctr, b, color, weight);
                     b++;
                     if (!go_on || b >= p.max_depth) {
                         float *o = p.samples + 3 * (size_t)out_idx;
                         o[0] = color.x; o[1] = color.y; o[2] = color.z;
-                        n_paths++;
+                        ended = true;
                         b = -1;
                     }
                 }
@@ -689,6 +697,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                 // in order, so lanes that fetch together still get adjacent pixels of one iteration.  (Wave-uniform
                 // control flow: every lane takes part in the votes, lane 0 does the atomic.)
                 bool want = wantS && b < 0;
+                n_paths += (unsigned)__popcll(hpt_ballot(ended));
                 for (;;) {
                     const unsigned long long need = hpt_ballot(want);
                     if (need == 0ull) break;
@@ -731,9 +740,11 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
             trav_node_steps(p, tv, stack, stride, spill);
         }
     }
-    atomicAdd(p.counters + 0, (unsigned long long)n_primary);
-    atomicAdd(p.counters + 1, (unsigned long long)n_bounce);
-    atomicAdd(p.counters + 2, (unsigned long long)n_paths);
+    if (lane == 0u) {
+        atomicAdd(p.counters + 0, (unsigned long long)n_primary);
+        atomicAdd(p.counters + 1, (unsigned long long)n_bounce);
+        atomicAdd(p.counters + 2, (unsigned long long)n_paths);
+    }
 #ifdef HPT_PROFILE_STEPS
     for (int k = 0; k < 3; k++) { atomicAdd(p.counters + 3 + k, prof_it[k]); atomicAdd(p.counters + 6 + k, prof_act[k]); }
     atomicAdd(p.counters + 9, prof_waitS); atomicAdd(p.counters + 10, prof_idle);
