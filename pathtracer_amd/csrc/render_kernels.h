@@ -236,16 +236,22 @@ __device__ __forceinline__ bool intersect_tri(f3 v1, f3 edge1, f3 edge2, f3 o, f
 // never read.  Float slots: a = 0..8, id_a = 9, id_b = 10, b = 11..19.
 #define HPT_PAIR_FLOAT4S 5
 #define HPT_PAIR_REF(first_pair, n) (~(((first_pair) << 6) | ((n) - 1)))
-// The other record form, for trees whose leaves hold (almost) one triangle each: one triangle per 48-B record,
-// the first half of a pair record on its own (a = 0..8, id = 9).  There the second-half test would serve a lane
-// or two per step, and a traversal kernel compiled without it runs 25 % faster on such a tree (C4, 10 M
-// triangles: profiles/r01_tuning.md), so the host picks the form per tree and the kernels exist in both.
+// The other record form, for trees whose leaves hold (almost) one triangle each (C4: 10 M triangles, 1.02 per
+// leaf): one triangle per 48-B record, the first half of a pair record on its own (a = 0..8, id = 9).  No
+// half-empty records (480 MB instead of 800 MB at C4) and a TRI step without the second-half test; the host
+// picks the form per tree and the traversal kernels exist in both.
 #define HPT_SINGLE_FLOAT4S 3
 __device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ rec, int half, f3 o, f3 d, float &t, int &id) {
     const float *f = reinterpret_cast<const float *>(rec) + (half ? 11 : 0);
     id = __float_as_int(reinterpret_cast<const float *>(rec)[9 + half]);
     return intersect_tri(mk3(f[0], f[1], f[2]), mk3(f[3], f[4], f[5]), mk3(f[6], f[7], f[8]), o, d, t);
 }
+
+// Keeps a load's address register(s) alive until its data has arrived, so the register allocator cannot hand them
+// to the load as its destination.  Whenever hipcc let the last of the NODE step's four loads overwrite its own
+// offset register, render_kernel ran 20-25 % slower on the HBM-bound C4 -- same instruction, cache and HBM
+// counts, twice the wave-cycles waiting for instruction issue (profiles/r01_tuning.md); C3 gains 1 %.
+#define HPT_KEEP_ADDRESS(addr, loaded) asm volatile("" : : "v"(addr), "v"(loaded))
 
 // ---- sphere / plane, ray_kernel.cl:524-602 ----
 // The primitive index is wave-uniform wherever this is called (every lane walks the whole list), and the list
@@ -415,7 +421,9 @@ __device__ __forceinline__ bool shade_bounce(const RenderParams &p, int id, floa
     Mat m;
     if (id >= 0) {
         const float4 *q = p.tris + 3 * (size_t)id;
-        normal = normalize3(cross3(mk3(q[1]), mk3(q[2])));
+        const float4 e1 = q[1], e2 = q[2];
+        HPT_KEEP_ADDRESS(q, e2.z);
+        normal = normalize3(cross3(mk3(e1), mk3(e2)));
         if (dot3(normal, r.d) > 0.0f) normal = -normal;
         // triangles use materials[0]: one address for every lane, read with scalar loads
         const __attribute__((address_space(4))) hpt_material *mm = (const __attribute__((address_space(4))) hpt_material *)p.mats;
@@ -507,7 +515,11 @@ __device__ __forceinline__ void trav_pop(const RenderParams &p, Trav &s, uint2 *
         s.sp--;
         uint2 e = make_uint2(0u, 0u);
         if (s.sp < p.stack_cap) e = stack[s.sp * stride];
-        if (s.sp >= p.stack_cap) e = spill[(size_t)(s.sp - p.stack_cap) * p.spill_stride];
+        if (s.sp >= p.stack_cap) {
+            const uint2 *a = spill + (size_t)(s.sp - p.stack_cap) * p.spill_stride;
+            e = *a;
+            HPT_KEEP_ADDRESS(a, e.x);
+        }
         if (__uint_as_float(e.y) < s.t) { ref = (int)e.x; break; }
     }
     s.cur = ref;
@@ -525,6 +537,7 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
                 const int packed = ~s.cur, rec = packed >> 6;
                 const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.pairs) + (unsigned)rec * 48u);
                 const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                HPT_KEEP_ADDRESS(rec, q2.y);
                 if (intersect_tri(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x),
                                   mk3(s.oxy.x, s.oxy.y, s.ozix.x), s.rd, s.t))
                     s.hit = __float_as_int(q2.y);
@@ -542,7 +555,8 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
             const float4 q0 = q[0], q1 = q[1], q2 = q[2];
             const bool two = left >= 2;
             float4 q3 = make_float4(0, 0, 0, 0), q4 = make_float4(0, 0, 0, 0);
-            if (two) { q3 = q[3]; q4 = q[4]; }
+            if (two) { const float4 *qb = q + 3; q3 = qb[0]; q4 = qb[1]; HPT_KEEP_ADDRESS(qb, q4.w); }
+            HPT_KEEP_ADDRESS(pair, q2.z);
             const f3 o = mk3(s.oxy.x, s.oxy.y, s.ozix.x);
             if (intersect_tri(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), o, s.rd, s.t))
                 s.hit = __float_as_int(q2.y);
@@ -565,10 +579,7 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
             const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + node_off);
             const float4 X = q[0], Y = q[1], Z = q[2];
             const int4 m = *reinterpret_cast<const int4 *>(q + 3);
-            // Keeps the offset register alive past the four loads, so none of them is given it as (part of) its
-            // destination: whenever hipcc let the last load overwrite its own address register the kernel ran
-            // 20-25 % slower on the HBM-bound C4 with identical instruction and traffic counts (profiles/r01_tuning.md).
-            asm volatile("" : : "v"(node_off), "v"(m.w));
+            HPT_KEEP_ADDRESS(node_off, m.w);
             const bool nx = s.flags & 1u, ny = s.flags & 2u, nz = s.flags & 4u;
             float t0, t1;
             unsigned long long M0, M1;                    // lanes whose child 0 / child 1 is hit with tmin < t
