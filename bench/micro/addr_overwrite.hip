@@ -1,0 +1,105 @@
+// Micro-benchmark (development): does a gather cost more when the load's DESTINATION registers include its own
+// ADDRESS register?  (profiles/r01_tuning.md: whenever hipcc gave the last of render_kernel's four node loads
+// its own offset register as part of the destination, the kernel ran 20-25 % slower on the HBM-bound C4.)
+//
+// Every lane chases node indices through a table of 64-B nodes: four global_load_dwordx4 of the four quarters
+// of one node, next index = word 0 of the node (a random permutation step).  The four loads are written in
+// assembly on fixed registers so that the only difference between the two kernels is the destination of the
+// last load: v[56:59] (apart from the offset in v40) or v[40:43] (on top of it).
+//   hipcc -O3 --offload-arch=gfx950 bench/micro/addr_overwrite.hip -o build/addr_overwrite && build/addr_overwrite
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int OVERLAP>
+__global__ void __launch_bounds__(256) chase(const uint4 *__restrict__ tab, unsigned mask, int active, int iters, unsigned *out) {
+    const unsigned lane = threadIdx.x & 63u, gl = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned idx = (gl * 2654435761u) & mask;
+    unsigned acc = 0;
+    if (lane < (unsigned)active) {
+        for (int i = 0; i < iters; i++) {
+            const unsigned off = idx << 6;
+            unsigned next, mix;
+            if (OVERLAP)
+                asm volatile("v_mov_b32 v40, %2\n"
+                             "s_nop 1\n"
+                             "global_load_dwordx4 v[44:47], v40, %3 offset:16\n"
+                             "global_load_dwordx4 v[48:51], v40, %3\n"
+                             "global_load_dwordx4 v[52:55], v40, %3 offset:48\n"
+                             "s_nop 0\n"
+                             "global_load_dwordx4 v[40:43], v40, %3 offset:32\n"
+                             "s_waitcnt vmcnt(0)\n"
+                             "v_mov_b32 %0, v48\n"
+                             "v_xor_b32 %1, v45, v53\n"
+                             "v_xor_b32 %1, %1, v41\n"
+                             : "=&v"(next), "=&v"(mix) : "v"(off), "s"(tab)
+                             : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                               "v56", "v57", "v58", "v59", "memory");
+            else
+                asm volatile("v_mov_b32 v40, %2\n"
+                             "s_nop 1\n"
+                             "global_load_dwordx4 v[44:47], v40, %3 offset:16\n"
+                             "global_load_dwordx4 v[48:51], v40, %3\n"
+                             "global_load_dwordx4 v[52:55], v40, %3 offset:48\n"
+                             "s_nop 0\n"
+                             "global_load_dwordx4 v[56:59], v40, %3 offset:32\n"
+                             "s_waitcnt vmcnt(0)\n"
+                             "v_mov_b32 %0, v48\n"
+                             "v_xor_b32 %1, v45, v53\n"
+                             "v_xor_b32 %1, %1, v57\n"
+                             : "=&v"(next), "=&v"(mix) : "v"(off), "s"(tab)
+                             : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                               "v56", "v57", "v58", "v59", "memory");
+            idx = next & mask;
+            acc += mix;
+        }
+    }
+    out[gl] = acc + idx;
+}
+
+int main() {
+    int dev = 0;
+    CK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, dev));
+    const int blocks = prop.multiProcessorCount * 6, threads = 256;          // 24 waves per CU, as render_kernel
+    unsigned *out;
+    CK(hipMalloc(&out, (size_t)blocks * threads * sizeof(unsigned)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const unsigned log_nodes[3] = {15, 20, 23};                               // 2 MB, 64 MB, 512 MB of 64-B nodes
+    for (unsigned ln : log_nodes) {
+        const size_t n = (size_t)1 << ln;
+        std::vector<uint4> h(n * 4);
+        // word 0 of node k = a pseudo-random next node (full-period LCG step, so chains do not collapse)
+        for (size_t k = 0; k < n; k++) {
+            unsigned nx = (unsigned)((k * 1664525u + 1013904223u) & (n - 1));
+            for (int q = 0; q < 4; q++) h[k * 4 + q] = make_uint4(q == 0 ? nx : (unsigned)k, (unsigned)k * 3u + q, 7u, 9u);
+        }
+        uint4 *tab;
+        CK(hipMalloc(&tab, n * 64));
+        CK(hipMemcpy(tab, h.data(), n * 64, hipMemcpyHostToDevice));
+        for (int active : {64, 28}) {
+            const int iters = ln >= 20 ? 400 : 2000;
+            float ms[2] = {0, 0};
+            for (int rep = 0; rep < 3; rep++)
+                for (int v = 0; v < 2; v++) {
+                    CK(hipEventRecord(e0));
+                    if (v) hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), active, iters, out);
+                    else hipLaunchKernelGGL(chase<0>, dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), active, iters, out);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipGetLastError());
+                    float t; CK(hipEventElapsedTime(&t, e0, e1));
+                    if (rep == 0 || t < ms[v]) ms[v] = t;
+                }
+            const double visits = (double)blocks * (threads / 64) * active * iters;
+            printf("table %4zu MB, %2d active lanes: separate dst %.3f ms (%.2f Gvisits/s)   dst over address %.3f ms (%.2f Gvisits/s)   ratio %.3f\n",
+                   n * 64 >> 20, active, ms[0], visits / ms[0] / 1e6, ms[1], visits / ms[1] / 1e6, ms[1] / ms[0]);
+        }
+        CK(hipFree(tab));
+    }
+    return 0;
+}

@@ -248,9 +248,10 @@ __device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ r
 }
 
 // Keeps a load's address register(s) alive until its data has arrived, so the register allocator cannot hand them
-// to the load as its destination.  Whenever hipcc let the last of the NODE step's four loads overwrite its own
-// offset register, render_kernel ran 20-25 % slower on the HBM-bound C4 -- same instruction, cache and HBM
-// counts, twice the wave-cycles waiting for instruction issue (profiles/r01_tuning.md); C3 gains 1 %.
+// to the load as its destination.  Every build in which hipcc let the last of the NODE step's four loads overwrite
+// its own offset register ran 20-25 % slower on the HBM-bound C4 -- same instruction, cache and HBM counts, twice
+// the wave-cycles waiting for instruction issue -- and with this guard none does (C3 gains 1 %).  An empirical
+// fix: the overlap alone does not reproduce the loss (profiles/r01_tuning.md, bench/micro/addr_overwrite.hip).
 #define HPT_KEEP_ADDRESS(addr, loaded) asm volatile("" : : "v"(addr), "v"(loaded))
 
 // ---- sphere / plane, ray_kernel.cl:524-602 ----
