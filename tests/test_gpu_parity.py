@@ -506,3 +506,41 @@ def test_cli_obj_to_png_end_to_end(tmp_path):
     for _ in range(7):
         o.iter_bounce(); o.iter_reconstruct(want)
     assert np.array_equal(np.asarray(Image.open(str(out)).convert("RGB")), orc.tonemap(want).reshape(64, 64, 3))
+
+
+def test_render_entry_point_one_and_two_ranks(tmp_path):
+    """python -m pathtracer_amd.render: OBJ -> PNG on one process, and on two processes started by
+    torch.distributed.run that share this GPU (gloo rehearsal of the N>1 path).  Tile shards give the oracle's
+    image byte for byte; sample shards give it within one 8-bit step (their sum is within 1e-5 relative)."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from oracle import binding as orc
+    from conftest import ROOT
+    s, bvh, _ = get_scene("cornell", width=64, height=64)
+    v = s["verts"].reshape(-1, 3)
+    obj = tmp_path / "cornell.obj"
+    with open(obj, "w") as f:
+        for x, y, z in v:
+            f.write("v %.9g %.9g %.9g\n" % (x, y, z))
+        for i in range(len(v) // 3):
+            f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    light = (0.0, -52.0, 5.0, 16.0, 12.0)
+    prims = scenes.sphere(light[:3], light[3], emissive=(light[4],) * 3)
+    o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], prims, scenes.make_material((0.6, 0.4, 0.2)),
+                        scenes.default_camera(), 64, 64, dict(s["cfg"], max_depth=4))
+    want = orc.tonemap(o.render(0, 5)[0]).reshape(64, 64, 3).astype(np.int32)
+    args = ["-m", "pathtracer_amd.render", "--obj", str(obj), "--w", "64", "--h", "64", "--spp", "5", "--depth", "4",
+            "--light"] + [repr(x) for x in light]
+    env = dict(os.environ, PYTHONPATH=ROOT, HPT_DIST_BACKEND="gloo")
+    port = 30500 + (os.getpid() % 2000)
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    for k, (cmd, tol) in enumerate([([sys.executable] + args, 0),
+                                    (launch + ["--master-port", str(port)] + args, 0),
+                                    (launch + ["--master-port", str(port + 1)] + args + ["--shard", "samples"], 1)]):
+        out = tmp_path / ("o%d.png" % k)
+        r = subprocess.run(cmd + ["--out", str(out)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.asarray(Image.open(str(out)).convert("RGB")).astype(np.int32)
+        assert np.abs(got - want).max() <= tol, k
