@@ -17,6 +17,7 @@
 
 #include "../../include/hpt/hpt.h"
 #include "render_kernels.h"
+#include "host/bvh.hpp"            // parallel_chunks, build_threads
 
 namespace {
 
@@ -163,15 +164,25 @@ int ensure_pairs(hpt_ctx *ctx) {
     bool singles = leaf_tris * 4 < n_leaves * 5;
     if (ctx->leaf_records > 0) singles = ctx->leaf_records == 1;
     const int rec_floats = singles ? 4 * HPT_SINGLE_FLOAT4S : 4 * HPT_PAIR_FLOAT4S;
-    std::vector<float> rec;
-    rec.reserve(singles ? leaf_tris * 12 : ((size_t)ctx->n_tris / 2 + wide.size() + 1) * 20);
-    auto repoint = [&](int32_t &ref) {
+    auto records_of = [&](int32_t ref) -> size_t {             // records a leaf reference needs
+        if (ref >= 0) return 0;
+        const size_t n = (size_t)((~ref & 63) + 1);
+        return singles ? n : (n + 1) / 2;
+    };
+    // first record of each node's leaves (root leaf first, then node order): sequential prefix sum, parallel fill
+    int32_t root = ctx->root_ref_tris;
+    std::vector<size_t> first_rec(wide.size() + 1);
+    size_t n_rec = records_of(root);
+    for (size_t i = 0; i < wide.size(); i++) { first_rec[i] = n_rec; n_rec += records_of(wide[i].ref0) + records_of(wide[i].ref1); }
+    first_rec[wide.size()] = n_rec;
+    if (n_rec >= (size_t)(1 << 25)) return fail(ctx, HPT_ERR_BVH, "too many triangle records");
+    std::vector<float> rec((n_rec + 1) * (size_t)rec_floats, 0.0f);   // one spare record: a pair load of the last single stays inside
+    auto repoint = [&](int32_t &ref, size_t at) {
         if (ref >= 0) return;
         const int packed = ~ref, first = packed >> 6, n = (packed & 63) + 1;
-        const int first_rec = (int)(rec.size() / (size_t)rec_floats);
-        for (int i = 0; i < n; i += singles ? 1 : 2) {
-            float r[20];
-            for (int k = 0; k < 20; k++) r[k] = 0.0f;
+        const size_t first_at = at;
+        for (int i = 0; i < n; i += singles ? 1 : 2, at++) {
+            float *r = rec.data() + at * (size_t)rec_floats;
             for (int h = 0; h < (singles ? 1 : 2) && i + h < n; h++) {
                 const hpt_triangle &t = ctx->h_tris[first + i + h];
                 float *f = r + (h ? 11 : 0);
@@ -180,15 +191,16 @@ int ensure_pairs(hpt_ctx *ctx) {
                 const int32_t id = first + i + h;
                 memcpy(r + 9 + h, &id, 4);
             }
-            rec.insert(rec.end(), r, r + rec_floats);
         }
-        ref = HPT_PAIR_REF(first_rec, n);
+        ref = HPT_PAIR_REF((int)first_at, n);
     };
-    int32_t root = ctx->root_ref_tris;
-    repoint(root);
-    for (WideNode &w : wide) { repoint(w.ref0); repoint(w.ref1); }
-    if (rec.size() / (size_t)rec_floats >= (size_t)(1 << 25)) return fail(ctx, HPT_ERR_BVH, "too many triangle records");
-    rec.resize(rec.size() + 8, 0.0f);
+    repoint(root, 0);
+    hpt::parallel_chunks(hpt::build_threads(), (long)wide.size(), [&](int, long b, long e) {
+        for (long i = b; i < e; i++) {
+            repoint(wide[i].ref0, first_rec[i]);
+            repoint(wide[i].ref1, first_rec[i] + records_of(ctx->h_wide[i].ref0));
+        }
+    });
     int rc = replace_buffer(ctx, ctx->d_nodes, wide.data(), wide.size() * sizeof(WideNode));
     if (rc) return rc;
     if ((rc = replace_buffer(ctx, ctx->d_pairs, rec.data(), rec.size() * sizeof(float)))) return rc;
