@@ -252,7 +252,11 @@ __device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ r
 // its own offset register ran 20-25 % slower on the HBM-bound C4 -- same instruction, cache and HBM counts, twice
 // the wave-cycles waiting for instruction issue -- and with this guard none does (C3 gains 1 %).  An empirical
 // fix: the overlap alone does not reproduce the loss (profiles/r01_tuning.md, bench/micro/addr_overwrite.hip).
+#ifdef HPT_NO_KEEP_ADDRESS           // development: the unguarded code, to reproduce the loss
+#define HPT_KEEP_ADDRESS(addr, loaded) ((void)0)
+#else
 #define HPT_KEEP_ADDRESS(addr, loaded) asm volatile("" : : "v"(addr), "v"(loaded))
+#endif
 
 // ---- sphere / plane, ray_kernel.cl:524-602 ----
 // The primitive index is wave-uniform wherever this is called (every lane walks the whole list), and the list
