@@ -578,6 +578,19 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
 // node_repeat_min lanes still have an interior node to test.
 __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
     for (;;) {
+#ifdef HPT_PROFILE_STEPS
+        {   // development build: how many NODE iterations have all their lanes at ONE node (a scalar load would do)
+            const bool in = (unsigned)s.cur < (unsigned)HPT_REF_IDLE;
+            const unsigned long long act = hpt_ballot(in);
+            const int first = __builtin_amdgcn_readfirstlane(in ? s.cur : -1);     // value of the first ACTIVE lane
+            const bool uni = act != 0ull && hpt_ballot(in && s.cur != first) == 0ull && in;
+            const unsigned long long U = hpt_ballot(uni);
+            if (act != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(act)) {
+                atomicAdd(p.counters + 11, 1ull); atomicAdd(p.counters + 13, (unsigned long long)__popcll(act));
+                if (U != 0ull) { atomicAdd(p.counters + 12, 1ull); atomicAdd(p.counters + 14, (unsigned long long)__popcll(act)); }
+            }
+        }
+#endif
         if ((unsigned)s.cur < (unsigned)HPT_REF_IDLE) {
             // 32-bit byte offset (n_wide < 2^25): saddr + voffset addressing, no 64-bit address math
             const unsigned node_off = (unsigned)s.cur << 6;
