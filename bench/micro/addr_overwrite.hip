@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) chase(const uint4 *__restrict__ tab, unsi
     const unsigned lane = threadIdx.x & 63u, gl = blockIdx.x * blockDim.x + threadIdx.x;
     // mixed: odd lanes chase inside the first 128 nodes (8 KB: L1 hits), even lanes over the whole table (misses),
     // so every load instruction has hit lanes and miss lanes
-    if (mixed && (lane & 1u)) mask = 127u;
+    if (mixed == 1 && (lane & 1u)) mask = 127u;
     unsigned idx = (gl * 2654435761u) & mask;
     unsigned acc = 0;
     if (lane < (unsigned)active) {
@@ -57,14 +57,16 @@ __global__ void __launch_bounds__(256) chase(const uint4 *__restrict__ tab, unsi
                              : "=&v"(next), "=&v"(mix) : "v"(off), "s"(tab)
                              : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
                                "v56", "v57", "v58", "v59", "memory");
-            idx = next & mask;
+            idx = (mixed == 2 && (i & 1) == 0) ? (idx ^ 1u) : (next & mask);      // mixed 2: then the other half of the same 128-B line
             acc += mix;
         }
     }
     out[gl] = acc + idx;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // addr_overwrite [log2_nodes mixed active]: one configuration only (for PMC calibration runs)
+    const int only_ln = argc > 3 ? atoi(argv[1]) : -1, only_mixed = argc > 3 ? atoi(argv[2]) : -1, only_active = argc > 3 ? atoi(argv[3]) : -1;
     int dev = 0;
     CK(hipSetDevice(dev));
     hipDeviceProp_t prop;
@@ -76,6 +78,7 @@ int main() {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const unsigned log_nodes[3] = {15, 20, 23};                               // 2 MB, 64 MB, 512 MB of 64-B nodes
     for (unsigned ln : log_nodes) {
+        if (only_ln >= 0 && (int)ln != only_ln) continue;
         const size_t n = (size_t)1 << ln;
         std::vector<uint4> h(n * 4);
         // word 0 of node k = a pseudo-random next node (full-period LCG step, so chains do not collapse)
@@ -86,8 +89,9 @@ int main() {
         uint4 *tab;
         CK(hipMalloc(&tab, n * 64));
         CK(hipMemcpy(tab, h.data(), n * 64, hipMemcpyHostToDevice));
-        for (int mixed : {0, 1})
+        for (int mixed : {0, 1, 2})
         for (int active : {64, 28}) {
+            if (only_ln >= 0 && (mixed != only_mixed || active != only_active)) continue;
             const int iters = ln >= 20 ? 400 : 2000;
             float ms[2] = {0, 0};
             for (int rep = 0; rep < 3; rep++)
@@ -102,8 +106,9 @@ int main() {
                     if (rep == 0 || t < ms[v]) ms[v] = t;
                 }
             const double visits = (double)blocks * (threads / 64) * active * iters;
+            printf("visits per launch %.0f (x 64 B = %.3f GB)\n", visits, visits * 64 / 1e9);
             printf("table %4zu MB, %s, %2d active lanes: separate dst %.3f ms (%.2f Gvisits/s)   dst over address %.3f ms (%.2f Gvisits/s)   ratio %.3f\n",
-                   n * 64 >> 20, mixed ? "odd lanes in 8 KB" : "all lanes anywhere", active, ms[0], visits / ms[0] / 1e6, ms[1], visits / ms[1] / 1e6, ms[1] / ms[0]);
+                   n * 64 >> 20, mixed == 2 ? "both halves of each line" : mixed ? "odd lanes in 8 KB" : "all lanes anywhere", active, ms[0], visits / ms[0] / 1e6, ms[1], visits / ms[1] / 1e6, ms[1] / ms[0]);
         }
         CK(hipFree(tab));
     }
