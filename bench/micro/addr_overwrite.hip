@@ -64,6 +64,34 @@ __global__ void __launch_bounds__(256) chase(const uint4 *__restrict__ tab, unsi
     out[gl] = acc + idx;
 }
 
+// The same chase with cache-policy bits on the loads (MOD = "nt", "sc1", "sc0 sc1", "sc0 sc1 nt"): does any of them make
+// an L2 miss fetch less than the whole 128-B line?
+#define CHASE_MOD(NAME, MOD) \
+__global__ void __launch_bounds__(256) NAME(const uint4 *__restrict__ tab, unsigned mask, int active, int iters, unsigned *out) { \
+    const unsigned lane = threadIdx.x & 63u, gl = blockIdx.x * blockDim.x + threadIdx.x; \
+    unsigned idx = (gl * 2654435761u) & mask, acc = 0; \
+    if (lane < (unsigned)active) \
+        for (int i = 0; i < iters; i++) { \
+            const unsigned off = idx << 6; \
+            unsigned next, mix; \
+            asm volatile("v_mov_b32 v40, %2\n s_nop 1\n" \
+                         "global_load_dwordx4 v[44:47], v40, %3 offset:16 " MOD "\n" \
+                         "global_load_dwordx4 v[48:51], v40, %3 " MOD "\n" \
+                         "global_load_dwordx4 v[52:55], v40, %3 offset:48 " MOD "\n" \
+                         "global_load_dwordx4 v[56:59], v40, %3 offset:32 " MOD "\n" \
+                         "s_waitcnt vmcnt(0)\n v_mov_b32 %0, v48\n v_xor_b32 %1, v45, v53\n v_xor_b32 %1, %1, v57\n" \
+                         : "=&v"(next), "=&v"(mix) : "v"(off), "s"(tab) \
+                         : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
+                           "v56", "v57", "v58", "v59", "memory"); \
+            idx = next & mask; acc += mix; \
+        } \
+    out[gl] = acc + idx; \
+}
+CHASE_MOD(chase_nt, "nt")
+CHASE_MOD(chase_sc1, "sc1")
+CHASE_MOD(chase_sc01, "sc0 sc1")
+CHASE_MOD(chase_sc01nt, "sc0 sc1 nt")
+
 int main(int argc, char **argv) {
     // addr_overwrite [log2_nodes mixed active]: one configuration only (for PMC calibration runs)
     const int only_ln = argc > 3 ? atoi(argv[1]) : -1, only_mixed = argc > 3 ? atoi(argv[2]) : -1, only_active = argc > 3 ? atoi(argv[3]) : -1;
@@ -109,6 +137,24 @@ int main(int argc, char **argv) {
             printf("visits per launch %.0f (x 64 B = %.3f GB)\n", visits, visits * 64 / 1e9);
             printf("table %4zu MB, %s, %2d active lanes: separate dst %.3f ms (%.2f Gvisits/s)   dst over address %.3f ms (%.2f Gvisits/s)   ratio %.3f\n",
                    n * 64 >> 20, mixed == 2 ? "both halves of each line" : mixed ? "odd lanes in 8 KB" : "all lanes anywhere", active, ms[0], visits / ms[0] / 1e6, ms[1], visits / ms[1] / 1e6, ms[1] / ms[0]);
+        }
+        if (only_ln < 0 || only_mixed == 3) {
+            typedef void (*K)(const uint4 *, unsigned, int, int, unsigned *);
+            const K ks[4] = {chase_nt, chase_sc1, chase_sc01, chase_sc01nt};
+            const char *names[4] = {"nt", "sc1", "sc0 sc1", "sc0 sc1 nt"};
+            const int iters = ln >= 20 ? 400 : 2000;
+            for (int k = 0; k < 4; k++) {
+                float best = 0;
+                for (int rep = 0; rep < 2; rep++) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(ks[k], dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), 64, iters, out);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+                    float t; CK(hipEventElapsedTime(&t, e0, e1));
+                    if (rep == 0 || t < best) best = t;
+                }
+                printf("table %4zu MB, loads with %-10s: %.3f ms (%.2f Gvisits/s)\n", n * 64 >> 20, names[k], best,
+                       (double)blocks * (threads / 64) * 64 * iters / best / 1e6);
+            }
         }
         CK(hipFree(tab));
     }
