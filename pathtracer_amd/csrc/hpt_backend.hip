@@ -78,7 +78,9 @@ struct hpt_ctx {
     bool timed = false;
     int n_cu = 256;
     int grid_waves = 0;
-    int shade_threshold = 24;        // scheduling knob of render_kernel (HPT_SHADE_THRESHOLD overrides; results do not depend on it)
+    int shade_threshold = 24;        // scheduling knob of render_kernel (results do not depend on it): 24, up to 40 with the length of the
+                                     // primitive list, which every ray that starts in a SHADE step walks (fill_params); HPT_SHADE_THRESHOLD fixes it
+    bool shade_threshold_fixed = false;
     int tris_per_trip = 8;
     int node_repeat_min = 24;
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
@@ -241,7 +243,10 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     p.n_work = p.n_slots;
     p.batch = 1; p.spp_base = spp_begin; p.spp_first = spp_begin; p.spp_stride = 1;
     p.raw_sample = raw;
-    p.shade_threshold = ctx->shade_threshold;
+    // the longer the primitive list, the dearer a SHADE step (129 primitives: ~6 000 instructions), the more lanes
+    // it should wait for: C5 24 / 32 / 40 / 48 -> 2 115 / 2 235 / 2 259 / 2 204 Mrays/s; C3 (1 primitive) is best at 24
+    p.shade_threshold = ctx->shade_threshold_fixed ? ctx->shade_threshold
+                                                   : ctx->shade_threshold + (ctx->n_prims / 8 < 16 ? ctx->n_prims / 8 : 16);
     p.tris_per_trip = ctx->tris_per_trip;
     p.node_repeat_min = ctx->node_repeat_min;
     p.fetch_chunk = ctx->fetch_chunk;
@@ -371,7 +376,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount;
-    if (const char *e = getenv("HPT_SHADE_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_threshold = v; }
+    if (const char *e = getenv("HPT_SHADE_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) { ctx->shade_threshold = v; ctx->shade_threshold_fixed = true; } }
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_LEAF_RECORDS")) ctx->leaf_records = !strcmp(e, "singles") ? 1 : !strcmp(e, "pairs") ? 2 : 0;
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
