@@ -465,6 +465,40 @@ def test_full_size_properties_c3():
         assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0
 
 
+def test_full_size_properties_c4(monkeypatch):
+    """BASELINE config C4 at full size (10 M triangles, 19.6 M reference nodes, 3840x2160), one sample per pixel:
+    (1) the two triangle-record forms and an LDS stack of one entry (everything through the HBM overflow) give the
+    same image bit for bit, (2) eight tile shards reassemble to it, (3) two pixel rows equal the oracle."""
+    s, bvh, o = get_scene("tenm")
+    w, h = s["width"], s["height"]
+    images = []
+    for env in (dict(HPT_LEAF_RECORDS="singles"), dict(HPT_LEAF_RECORDS="pairs", HPT_STACK_CAP="1")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        be = backend_for(s, bvh)
+        a = dev_image(be)
+        be.render(0, 1, a.data_ptr()); be.synchronize()
+        assert be.stats()["paths"] == w * h
+        images.append(a)
+        monkeypatch.delenv("HPT_STACK_CAP", raising=False)
+    assert torch.equal(images[0].view(torch.int32), images[1].view(torch.int32))
+    c = dev_image(be)
+    slabs = []
+    for r in range(8):
+        be.set_shard(r, 8)
+        d = dev_image(be)
+        be.render(0, 1, d.data_ptr())
+        slab = torch.empty(be.slab_floats(), dtype=torch.float32, device="cuda")
+        be.pack_tiles(d.data_ptr(), slab.data_ptr()); be.synchronize()
+        slabs.append(slab)
+    be.unpack_tiles(torch.cat(slabs).data_ptr(), c.data_ptr()); be.synchronize()
+    assert torch.equal(images[0].view(torch.int32), c.view(torch.int32))
+    img = images[0].cpu().numpy().reshape(-1, 3)
+    for row in (700, 1500):
+        oimg, _ = o.render(0, 1, px_begin=row * w, px_end=(row + 1) * w)
+        assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0
+
+
 def test_cli_obj_to_png_end_to_end(tmp_path):
     """The headless replacement of main.cpp: OBJ file -> load_obj -> BVH build -> upload -> render -> PNG, all in the
     C++ host side; the PNG must equal the oracle's image through the reference's 8-bit conversion."""
