@@ -1,4 +1,4 @@
-"""pathtracer_amd — MI355X (gfx950) HIP render path for brianli/pathtracer behind a C-ABI.
+"""pathtracer_amd — MI355X (gfx950) HIP render path for brianrli/pathtracer behind a C-ABI.
 
 csrc/            HIP kernels + C-ABI (include/hpt/hpt.h) + C++ host side (facade, BVH, OBJ, image out)
 api.py           ctypes binding (Backend = the C-ABI, Pathtracer = the C++ facade)
