@@ -81,6 +81,40 @@ def test_glossy_and_refractive_materials_bit_exact():
             assert mismatch(be.kernel_execute(it), o2.kernel_execute(it)[0]) == 0
 
 
+def _camera(eye, n, u, v):
+    cam = np.zeros((), api.CAMERA)
+    cam["eye"] = (*eye, 0); cam["n"] = (*n, 0); cam["u"] = (*u, 0); cam["v"] = (*v, 0)
+    return cam
+
+
+@pytest.mark.parametrize("cam", [
+    ((30.0, -20.0, -150.0), (-0.19, 0.13, -0.97), (0.98, 0.0, -0.19), (0.02, 0.99, 0.13)),      # off axis, rotated basis
+    ((0.0, 0.0, -200.0), (0.0, 0.0, -1.0), (0.3, 0.0, 0.0), (0.0, 0.5, 0.0)),                  # narrow, anisotropic field of view
+    ((5.0, 10.0, -20.0), (0.0, 0.0, -1.0), (2.5, 0.5, 0.0), (-0.5, 2.0, 0.0)),                 # inside the scene, wide, skewed
+    ((80.0, 0.0, -200.0), (0.0, 0.0, -1.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)),                 # every ray (0,0,1): 1/0 = inf, (lo-o)*inf = NaN on the wall planes
+    ((-200.0, -80.0, 80.0), (-1.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)),               # every ray (1,0,0), origin on two box planes
+    ((0.0, 200.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1e-30), (1e-30, 0.0, 0.0)),                # (0,-1,0) plus denormal-sized offsets
+])
+def test_other_cameras_bit_exact(cam):
+    """hpt_set_camera with cameras other than the reference's fixed one (pathtracer.cpp:224-263), including rays with
+    exactly zero direction components -- reciprocals +-inf, plane distances NaN where the origin lies on a box
+    plane -- so the packed slab test's NaN polarity is compared with the oracle's comparison form on real trees."""
+    from oracle import binding as orc
+    camera = _camera(*cam)
+    for name, kw in [("cornell", dict(width=96, height=96)), ("random", dict(n=2000, seed=1, width=64, height=64))]:
+        s, bvh, _ = get_scene(name, **kw)
+        s = dict(s, camera=camera)
+        o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], s["primitives"], s["materials"], camera,
+                            s["width"], s["height"], s["cfg"])
+        be = backend_for(s, bvh)
+        hit, t = be.primary_hits(2)
+        oh, ot, _ = o.primary_hits(2)
+        assert np.array_equal(hit, oh) and mismatch(t, ot) == 0
+        d = dev_image(be)
+        be.render(0, 3, d.data_ptr()); be.synchronize()
+        assert mismatch(d.cpu().numpy(), o.render(0, 3)[0]) == 0
+
+
 def test_running_mean_fused_and_stepwise():
     """hpt_render over [0,n) == n x hpt_render_sample == oracle render (pathtracer.cpp:200-217)."""
     s, bvh, o = get_scene("cornell", width=64, height=64)
