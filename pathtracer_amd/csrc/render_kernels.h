@@ -249,7 +249,7 @@ __device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ r
 
 // Keeps a load's address register(s) alive until its data has arrived, so the register allocator cannot hand them
 // to the load as its destination.  Every build in which hipcc let the last of the NODE step's four loads overwrite
-// its own offset register ran 20-25 % slower on the HBM-bound C4 -- same instruction, cache and HBM counts, twice
+// its own offset register ran 20-25 % slower on C4 (tree streamed from HBM) -- same instruction, cache and HBM counts, twice
 // the wave-cycles waiting for instruction issue -- and with this guard none does (C3 gains 1 %).  An empirical
 // fix: the overlap alone does not reproduce the loss (profiles/r01_tuning.md, bench/micro/addr_overwrite.hip).
 #ifdef HPT_NO_KEEP_ADDRESS           // development: the unguarded code, to reproduce the loss
