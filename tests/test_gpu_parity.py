@@ -612,3 +612,48 @@ def test_render_entry_point_one_and_two_ranks(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         got = np.asarray(Image.open(str(out)).convert("RGB")).astype(np.int32)
         assert np.abs(got - want).max() <= tol, k
+
+
+def test_plain_c_example_matches_oracle(tmp_path):
+    """examples/minimal.c, built with gcc against libhpt.so: a procedural mesh through hpt_host_build_bvh, the
+    uploads and hpt_render_sample (host buffers, the reference-shaped progressive call) to a PNG that equals the
+    oracle's image of the same scene."""
+    import math
+    import os
+    import subprocess
+    from PIL import Image
+    from oracle import binding as orc
+    from conftest import ROOT
+    exe = tmp_path / "minimal"
+    lib_dir = os.path.join(ROOT, "pathtracer_amd")
+    r = subprocess.run(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "minimal.c"),
+                        "-L" + lib_dir, "-lhpt", "-Wl,-rpath," + lib_dir, "-Wl,-rpath-link,/opt/rocm/lib", "-lm", "-o", str(exe)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "m.png"
+    r = subprocess.run([str(exe), str(out), "96", "64", "5"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    # the same mesh, in fp32 exactly as the C program computes it (sinf/cosf of glibc on both sides)
+    import ctypes
+    m = ctypes.CDLL("libm.so.6")
+    m.sinf.restype = m.cosf.restype = ctypes.c_float
+    m.sinf.argtypes = m.cosf.argtypes = [ctypes.c_float]
+    f32 = np.float32
+    pi = f32(3.14159265358979)
+    verts = []
+    for ring in range(8):
+        for seg in range(16):
+            p = []
+            for k in range(4):
+                th = f32(f32(pi * f32(ring + (k >> 1))) / f32(8)); ph = f32(f32(f32(f32(2.0) * pi) * f32(seg + (k & 1))) / f32(16))
+                st, ct, sp, cp = f32(m.sinf(th)), f32(m.cosf(th)), f32(m.sinf(ph)), f32(m.cosf(ph))
+                p.append((f32(f32(f32(60.0) * st) * cp), f32(f32(60.0) * ct), f32(f32(f32(60.0) * st) * sp)))
+            for t in ((0, 1, 2), (2, 1, 3)):
+                verts.append([p[i] for i in t])
+    verts = np.array(verts, np.float32)
+    bvh = api.build_bvh(verts)
+    light = scenes.sphere((40.0, -160.0, -60.0), 50.0, emissive=(12.0, 12.0, 12.0))
+    o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], light, scenes.make_material((0.6, 0.4, 0.2)),
+                        scenes.default_camera(), 96, 64, dict(scenes.DEFAULT_CFG))
+    want = orc.tonemap(o.render(0, 5)[0]).reshape(64, 96, 3)
+    assert np.array_equal(np.asarray(Image.open(str(out)).convert("RGB")), want)

@@ -150,6 +150,25 @@ def test_c_abi_exports_every_declared_symbol():
         assert getattr(L, name) is not None
 
 
+def test_host_header_symbols_and_plain_c_example(tmp_path):
+    """include/hpt/host.h: every declared entry point is exported; both headers are plain C, and the C example
+    (examples/minimal.c) compiles with -Wall -Wextra -Werror and links against libhpt.so with gcc."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "hpt", "host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(hpt_host_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == ["hpt_host_build_bvh", "hpt_host_load_obj", "hpt_host_save_png", "hpt_host_save_png_rgb8", "hpt_host_save_ppm"]
+    L = C.CDLL(api.LIB_PATH)
+    for name in declared:
+        assert getattr(L, name) is not None
+    exe = tmp_path / "minimal"
+    r = subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "minimal.c"), "-L" + os.path.dirname(api.LIB_PATH), "-lhpt",
+                        "-Wl,-rpath," + os.path.dirname(api.LIB_PATH), "-Wl,-rpath-link,/opt/rocm/lib", "-lm", "-o", str(exe)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
