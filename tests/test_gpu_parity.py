@@ -657,3 +657,55 @@ def test_plain_c_example_matches_oracle(tmp_path):
                         scenes.default_camera(), 96, 64, dict(scenes.DEFAULT_CFG))
     want = orc.tonemap(o.render(0, 5)[0]).reshape(64, 96, 3)
     assert np.array_equal(np.asarray(Image.open(str(out)).convert("RGB")), want)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_randomized_scenes_bit_exact(case):
+    """Twenty-four seeded random configurations -- triangle soups of 12..3000 triangles of varying extent and size, random
+    analytic primitives (spheres and planes: diffuse, glossy, glass, emissive), random triangle material, camera,
+    depth limit, Russian-roulette start, diffuse factor and RNG seed -- primary hits and two radiance samples against
+    the oracle, bit for bit."""
+    from oracle import binding as orc
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice([12, 13, 40, 300, 1500, 3000]))
+    s = scenes.scene("random", n=n, seed=int(rng.integers(1, 1 << 20)), extent=float(rng.uniform(20, 120)),
+                     size=float(rng.uniform(2, 60)), width=int(rng.integers(17, 80)), height=int(rng.integers(9, 70)))
+    prims = [scenes.sphere(tuple(rng.uniform(-150, 150, 3)), float(rng.uniform(10, 60)), emissive=tuple(rng.uniform(4, 16, 3)))]
+    for _ in range(int(rng.integers(0, 6))):
+        kind = int(rng.integers(0, 4))
+        c = tuple(rng.uniform(-90, 90, 3))
+        if kind == 0:
+            prims.append(scenes.sphere(c, float(rng.uniform(3, 30)), diffuse=tuple(rng.uniform(0, 1, 3))))
+        elif kind == 1:
+            prims.append(scenes.sphere(c, float(rng.uniform(3, 30)), diffuse=tuple(rng.uniform(0, 1, 3)),
+                                       specular=tuple(rng.uniform(0, 1, 3)), ior=float(rng.uniform(1.1, 2.5))))
+        elif kind == 2:
+            prims.append(scenes.sphere(c, float(rng.uniform(3, 30)), ior=float(rng.uniform(1.1, 2.5)), transmissive=True))
+        else:
+            nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+            prims.append(scenes.plane(c, tuple(nrm), tuple(rng.uniform(0, 1, 3)), ptype=int(rng.choice([1, 1, 4]))))
+    mat_kind = int(rng.integers(0, 3))
+    mats = scenes.make_material(tuple(rng.uniform(0, 1, 3)),
+                                specular=tuple(rng.uniform(0, 1, 3)) if mat_kind == 1 else (0, 0, 0),
+                                ior=float(rng.uniform(1.0, 2.2)), transmissive=mat_kind == 2)
+    eye = rng.uniform(-60, 60, 3) + np.array([0, 0, -200.0])
+    nvec = -(np.zeros(3) - eye) / np.linalg.norm(eye)          # n points from the target to the eye
+    up = np.array([0.0, 1.0, 0.0])
+    u = np.cross(up, -nvec); u /= np.linalg.norm(u)
+    v = np.cross(-nvec, u)
+    camera = _camera(tuple(eye), tuple(nvec), tuple(u * rng.uniform(0.4, 1.5)), tuple(v * rng.uniform(0.4, 1.5)))
+    cfg = dict(max_depth=int(rng.integers(1, 21)), rr_start=int(rng.integers(0, 6)), diffuse_scale=float(rng.choice([1.0, 2.0, 0.7])),
+               seed=int(rng.integers(0, 1 << 32)))
+    s = dict(s, primitives=np.concatenate(prims), materials=mats, camera=camera, cfg=cfg)
+    bvh = api.build_bvh(s["verts"])
+    o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], s["primitives"], s["materials"], camera,
+                        s["width"], s["height"], cfg)
+    be = backend_for(s, bvh)
+    hit, t = be.primary_hits(1)
+    oh, ot, _ = o.primary_hits(1)
+    assert np.array_equal(hit, oh) and mismatch(t, ot) == 0
+    for it in (0, 37):
+        assert mismatch(be.kernel_execute(it), o.kernel_execute(it)[0]) == 0
+    d = dev_image(be)
+    be.render(0, 4, d.data_ptr()); be.synchronize()
+    assert mismatch(d.cpu().numpy(), o.render(0, 4)[0]) == 0
