@@ -659,12 +659,10 @@ def test_plain_c_example_matches_oracle(tmp_path):
     assert np.array_equal(np.asarray(Image.open(str(out)).convert("RGB")), want)
 
 
-@pytest.mark.parametrize("case", range(24))
-def test_randomized_scenes_bit_exact(case):
-    """Twenty-four seeded random configurations -- triangle soups of 12..3000 triangles of varying extent and size, random
-    analytic primitives (spheres and planes: diffuse, glossy, glass, emissive), random triangle material, camera,
-    depth limit, Russian-roulette start, diffuse factor and RNG seed -- primary hits and two radiance samples against
-    the oracle, bit for bit."""
+def _random_case(case):
+    """Seeded random configuration: a triangle soup of 12..3000 triangles of varying extent and size, random analytic
+    primitives (spheres and planes: diffuse, glossy, glass, emissive), random triangle material, camera, depth
+    limit, Russian-roulette start, diffuse factor and RNG seed.  -> (scene dict, bvh, oracle scene)"""
     from oracle import binding as orc
     rng = np.random.default_rng(1000 + case)
     n = int(rng.choice([12, 13, 40, 300, 1500, 3000]))
@@ -700,6 +698,14 @@ def test_randomized_scenes_bit_exact(case):
     bvh = api.build_bvh(s["verts"])
     o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], s["primitives"], s["materials"], camera,
                         s["width"], s["height"], cfg)
+    return s, bvh, o
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_randomized_scenes_bit_exact(case):
+    """Twenty-four random configurations (_random_case): primary hits, two radiance samples and a 4-sample running
+    mean against the oracle, bit for bit."""
+    s, bvh, o = _random_case(case)
     be = backend_for(s, bvh)
     hit, t = be.primary_hits(1)
     oh, ot, _ = o.primary_hits(1)
@@ -709,3 +715,22 @@ def test_randomized_scenes_bit_exact(case):
     d = dev_image(be)
     be.render(0, 4, d.data_ptr()); be.synchronize()
     assert mismatch(d.cpu().numpy(), o.render(0, 4)[0]) == 0
+
+
+@pytest.mark.parametrize("case", range(100, 108))
+def test_randomized_iterative_pipeline_bit_exact(case):
+    """Eight random configurations through the live frame loop (hpt_first_bounce, then bounce + reconstruct calls):
+    image, per-pixel path counters and ray counters equal the oracle's after every call."""
+    s, bvh, o = _random_case(case)
+    be = backend_for(s, bvh)
+    d = dev_image(be)
+    want = np.zeros((s["width"] * s["height"], 3), np.float32)
+    be.first_bounce(); o.iter_first_bounce()
+    for k in range(9):
+        be.bounce(); o.iter_bounce()
+        be.reconstruct_paths(d.data_ptr()); o.iter_reconstruct(want)
+        be.synchronize()
+        assert mismatch(d.cpu().numpy(), want) == 0, k
+        assert np.array_equal(be.path_counts(), o.iter_px["completed"]), k
+    st = be.stats()
+    assert st["rays_primary"] == o.iter_st.rays_primary and st["rays_bounce"] == o.iter_st.rays_bounce
