@@ -34,6 +34,40 @@ def test_host_bvh_is_order_exact(name, kw):
     assert b["depth"] == depth.max()
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_host_bvh_randomized_inputs_are_order_exact(case, monkeypatch):
+    """Seeded adversarial inputs for the order-exact builder, 1 to 7 host threads: coordinates snapped to a coarse
+    grid (ties in the longest-axis choice and in the bucket index), duplicated triangles (identical centroids: the
+    n <= 24 leaf branch, bvh.cpp:174-193), all triangles in one plane or on one line (zero extents), huge and tiny
+    coordinates."""
+    rng = np.random.default_rng(500 + case)
+    n = int(rng.choice([12, 13, 24, 25, 26, 100, 999, 5000]))
+    kind = case % 8
+    v = rng.uniform(-100, 100, (n, 3, 3)).astype(np.float32)
+    if kind == 1:
+        v = np.round(v / 25.0) * 25.0                                   # coarse grid: many equal centroid coordinates
+    elif kind == 2:
+        v[n // 3:] = v[0]                                               # two thirds identical triangles
+    elif kind == 3:
+        v[:, :, 1] = 7.0                                                # all in the plane y = 7
+    elif kind == 4:
+        v[:, :, 1] = 0.0; v[:, :, 2] = -3.0                             # all on one line
+    elif kind == 5:
+        v *= np.float32(1e18)
+    elif kind == 6:
+        v *= np.float32(1e-30)
+    elif kind == 7:
+        v = np.round(v / 50.0) * 50.0; v[n // 2:] = v[: n - n // 2]     # grid + duplicates
+    v = np.ascontiguousarray(v, np.float32)
+    monkeypatch.setenv("HPT_BUILD_THREADS", str(1 + case % 7))
+    monkeypatch.setenv("HPT_BUILD_TASK_SIZE", str(int(rng.choice([0, 16, 200]))))
+    b = api.build_bvh(v)
+    ob, oi, oo = orc.build_bvh(v)
+    assert len(b["bbox"]) == len(ob) and b["bbox"].tobytes() == ob.tobytes() and b["info"].tobytes() == oi.tobytes()
+    assert np.array_equal(b["order"], oo)
+    assert b["triangles"].tobytes() == orc.make_triangles(v, oo).tobytes()
+
+
 @pytest.mark.parametrize("threads,task_size", [(1, 0), (5, 25), (3, 100), (16, 4000)])
 @pytest.mark.parametrize("name,kw", [("random", dict(n=2000, seed=1)), ("degenerate", dict(n_same=200, n_other=30)), ("bunny", {})])
 def test_host_bvh_parallel_build_is_thread_invariant(monkeypatch, name, kw, threads, task_size):
@@ -127,6 +161,44 @@ def test_obj_reader_matches_oracle_and_extends(tmp_path):
     r.write_text("v 0 0 0\nf 1 2 3\n")        # index out of range: the reference reads out of bounds, this one fails
     with pytest.raises(api.HptError):
         api.load_obj(str(r))
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_obj_reader_randomized_against_oracle(tmp_path, case):
+    """Seeded files of the kind the reference's load_obj reads (`v x y z`, `f a b c`), with the number spellings
+    fscanf accepts (exponents, signs, bare dots), tabs and repeated blanks, blank lines, comments and unknown
+    records, with and without a final newline, and padded to exact multiples of the page size (the reader maps
+    the file): same vertex list as the oracle's restatement of obj_reader.cpp."""
+    rng = np.random.default_rng(900 + case)
+    def num(x):
+        forms = ["%.9g" % x, "%.8e" % x, "%+.9g" % x, "%.9gE0" % x]
+        if x == int(x):
+            forms += ["%d" % int(x), "%d." % int(x)]
+        if 0 < abs(x) < 1:
+            forms.append(("%.9g" % x).replace("0.", ".", 1))
+        return forms[int(rng.integers(len(forms)))]
+    def gap():
+        return [" ", "  ", "\t", " \t "][int(rng.integers(4))]
+    nv = int(rng.integers(3, 400)) if case % 3 else int(rng.integers(4000, 6000))     # the big ones are above the mapping threshold (64 KB)
+    lines = []
+    for i in range(nv):
+        x = rng.choice([rng.uniform(-1e3, 1e3), float(rng.integers(-50, 50)), rng.uniform(-1, 1) * 1e-5, rng.uniform(-1, 1) * 1e20], 3)
+        lines.append("v" + gap() + num(float(np.float32(x[0]))) + gap() + num(float(np.float32(x[1]))) + gap() + num(float(np.float32(x[2]))))
+        if rng.random() < 0.1:
+            lines.append(["", "# a comment", "vn 0 0 1", "vt 0.5 0.5", "g group", "s off"][int(rng.integers(6))])
+    for _ in range(int(rng.integers(1, 300))):
+        a, b, c = rng.integers(1, nv + 1, 3)
+        lines.append("f" + gap() + "%d" % a + gap() + "%d" % b + gap() + "%d" % c)
+    text = "\n".join(lines) + ("\n" if case % 2 == 0 else "")
+    if case % 3 == 0:                                   # exactly k pages: no zero byte behind the last number in a mapping
+        page = os.sysconf("SC_PAGESIZE")
+        pad = (-len(text)) % page
+        text = "#" + "x" * (pad - 2) + "\n" + text if pad >= 2 else text
+    p = tmp_path / "r.obj"
+    p.write_text(text)
+    n, want = orc.load_obj(str(p))
+    got = api.load_obj(str(p))
+    assert got.shape == want.shape and got.tobytes() == want.tobytes()
 
 
 def test_png_writer_round_trip(tmp_path):
