@@ -189,6 +189,9 @@ def main():
                         "bytes_per_primary_ray": 40.0 * costs["nodes_per_primary_ray"] + 48.0 * costs["tris_per_primary_ray"] + 144.0,
                         "bytes_per_bounce_ray": 40.0 * costs["nodes_per_bounce_ray"] + 48.0 * costs["tris_per_bounce_ray"] + 144.0,
                         "l1_gather": gather,
+                        # SURVEY.md 8d asks for these beside the HBM fraction (same PMC run as `traffic`)
+                        "pmc": ({k: pmc[k] for k in ("l2_hit_rate", "l1_miss_to_l2_frac", "valu_busy_frac_of_cu_time", "lane_utilisation") if k in pmc}
+                                if traffic is not None else None),
                         "note": ("BVH+triangles (%.0f MB) are cache-resident, so algorithmic bytes/s can exceed the HBM peak; "
                                  "the measured limiter is the vector-L1 gather rate (l1_gather); see DESIGN.md §Roofline"
                                  if scene_mb <= 256 else
