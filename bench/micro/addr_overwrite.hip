@@ -1,13 +1,14 @@
-// Micro-benchmark (development): does a gather cost more when the load's DESTINATION registers include its own
-// ADDRESS register?  (profiles/r01_tuning.md: whenever hipcc gave the last of render_kernel's four node loads
-// its own offset register as part of the destination, the kernel ran 20-25 % slower on the HBM-bound C4.)
+// Micro-benchmark (development): what about the four loads of a 64-B node makes them slow?
+// (profiles/r01_tuning.md: every build in which hipcc gave the last of render_kernel's four node loads its own offset
+// register as part of the destination ran 20-25 % slower on C4.)
 //
 // Every lane chases node indices through a table of 64-B nodes: four global_load_dwordx4 of the four quarters
 // of one node, next index = word 0 of the node (a random permutation step).  The four loads are written in
-// assembly on fixed registers so that the only difference between the two kernels is the destination of the
-// last load: v[56:59] (apart from the offset in v40) or v[40:43] (on top of it).  Result on MI355X: no difference
-// (ratio 0.98-1.01) for 2 MB / 64 MB / 512 MB tables, 64 or 28 active lanes, all lanes missing or hit and miss lanes
-// mixed in every load -- the overlap alone is not what slows render_kernel down.
+// assembly on fixed registers.  chase<0> / chase<1>: the destination of the last load apart from the offset register
+// (v[56:59], offset in v40) or on top of it (v[40:43]) -- both with the `s_nop 0` that hipcc puts in front of such a load.
+// chase<2>: the four loads WITHOUT that s_nop, as one uninterrupted group (in render_kernel one s_nop inside the
+// group costs 23 % at C4).  Also: cache-policy bits on the loads, and visiting both halves of each 128-B line
+// (FETCH_SIZE calibration).
 //   hipcc -O3 --offload-arch=gfx950 bench/micro/addr_overwrite.hip -o build/addr_overwrite && build/addr_overwrite
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -27,7 +28,21 @@ __global__ void __launch_bounds__(256) chase(const uint4 *__restrict__ tab, unsi
         for (int i = 0; i < iters; i++) {
             const unsigned off = idx << 6;
             unsigned next, mix;
-            if (OVERLAP)
+            if (OVERLAP == 2)
+                asm volatile("v_mov_b32 v40, %2\n"
+                             "s_nop 1\n"
+                             "global_load_dwordx4 v[44:47], v40, %3 offset:16\n"
+                             "global_load_dwordx4 v[48:51], v40, %3\n"
+                             "global_load_dwordx4 v[52:55], v40, %3 offset:48\n"
+                             "global_load_dwordx4 v[56:59], v40, %3 offset:32\n"
+                             "s_waitcnt vmcnt(0)\n"
+                             "v_mov_b32 %0, v48\n"
+                             "v_xor_b32 %1, v45, v53\n"
+                             "v_xor_b32 %1, %1, v57\n"
+                             : "=&v"(next), "=&v"(mix) : "v"(off), "s"(tab)
+                             : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+                               "v56", "v57", "v58", "v59", "memory");
+            else if (OVERLAP)
                 asm volatile("v_mov_b32 v40, %2\n"
                              "s_nop 1\n"
                              "global_load_dwordx4 v[44:47], v40, %3 offset:16\n"
@@ -121,11 +136,12 @@ int main(int argc, char **argv) {
         for (int active : {64, 28}) {
             if (only_ln >= 0 && (mixed != only_mixed || active != only_active)) continue;
             const int iters = ln >= 20 ? 400 : 2000;
-            float ms[2] = {0, 0};
+            float ms[3] = {0, 0, 0};
             for (int rep = 0; rep < 3; rep++)
-                for (int v = 0; v < 2; v++) {
+                for (int v = 0; v < 3; v++) {
                     CK(hipEventRecord(e0));
-                    if (v) hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), active, iters, mixed, out);
+                    if (v == 2) hipLaunchKernelGGL(chase<2>, dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), active, iters, mixed, out);
+                    else if (v) hipLaunchKernelGGL(chase<1>, dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), active, iters, mixed, out);
                     else hipLaunchKernelGGL(chase<0>, dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), active, iters, mixed, out);
                     CK(hipEventRecord(e1));
                     CK(hipEventSynchronize(e1));
@@ -135,8 +151,10 @@ int main(int argc, char **argv) {
                 }
             const double visits = (double)blocks * (threads / 64) * active * iters;
             printf("visits per launch %.0f (x 64 B = %.3f GB)\n", visits, visits * 64 / 1e9);
-            printf("table %4zu MB, %s, %2d active lanes: separate dst %.3f ms (%.2f Gvisits/s)   dst over address %.3f ms (%.2f Gvisits/s)   ratio %.3f\n",
-                   n * 64 >> 20, mixed == 2 ? "both halves of each line" : mixed ? "odd lanes in 8 KB" : "all lanes anywhere", active, ms[0], visits / ms[0] / 1e6, ms[1], visits / ms[1] / 1e6, ms[1] / ms[0]);
+            printf("table %4zu MB, %s, %2d active lanes: s_nop in the group, separate dst %.3f ms (%.2f Gvisits/s), dst over address %.3f ms (ratio %.3f); "
+                   "no s_nop %.3f ms (%.2f Gvisits/s, ratio %.3f)\n",
+                   n * 64 >> 20, mixed == 2 ? "both halves of each line" : mixed ? "odd lanes in 8 KB" : "all lanes anywhere", active, ms[0], visits / ms[0] / 1e6,
+                   ms[1], ms[1] / ms[0], ms[2], visits / ms[2] / 1e6, ms[2] / ms[0]);
         }
         if (only_ln < 0 || only_mixed == 3) {
             typedef void (*K)(const uint4 *, unsigned, int, int, unsigned *);

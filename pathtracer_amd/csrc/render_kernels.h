@@ -248,10 +248,11 @@ __device__ __forceinline__ bool intersect_pair_half(const float4 *__restrict__ r
 }
 
 // Keeps a load's address register(s) alive until its data has arrived, so the register allocator cannot hand them
-// to the load as its destination.  Every build in which hipcc let the last of the NODE step's four loads overwrite
-// its own offset register ran 20-25 % slower on C4 (tree streamed from HBM) -- same instruction, cache and HBM counts, twice
-// the wave-cycles waiting for instruction issue -- and with this guard none does (C3 gains 1 %).  An empirical
-// fix: the overlap alone does not reproduce the loss (profiles/r01_tuning.md, bench/micro/addr_overwrite.hip).
+// to the load as its destination.  When hipcc does that to the last of the NODE step's four loads it must put an
+// s_nop in front of it (the earlier loads still read the register), and that ONE s_nop inside the group of four
+// loads of one line costs 23 % on C4 (tree streamed from HBM) and 1 % on C3: the loads no longer reach the L1
+// back to back (profiles/r01_tuning.md; bench/micro/addr_overwrite.hip reproduces it;
+// tests/test_host.py::test_node_loads_form_one_uninterrupted_group checks the built code object).
 #ifdef HPT_NO_KEEP_ADDRESS           // development: the unguarded code, to reproduce the loss
 #define HPT_KEEP_ADDRESS(addr, loaded) ((void)0)
 #else

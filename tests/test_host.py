@@ -241,6 +241,59 @@ def test_host_header_symbols_and_plain_c_example(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_node_loads_form_one_uninterrupted_group():
+    """The four 16-B loads of a 64-B node must be issued back to back in every traversal kernel of the built library:
+    one s_nop between them (hipcc puts it there when it lets the last load overwrite its own address register)
+    costs 23 % on a tree that streams from HBM (profiles/r01_tuning.md; HPT_KEEP_ADDRESS in render_kernels.h keeps
+    the compiler from doing it).  Checked on the gfx950 code object inside libhpt.so."""
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    data = open(api.LIB_PATH, "rb").read()
+    i, co = 0, None
+    while True:                                          # the embedded AMDGPU ELF (e_machine 224)
+        i = data.find(b"\x7fELF", i)
+        assert i >= 0, "no gfx950 code object in libhpt.so"
+        if int.from_bytes(data[i + 18:i + 20], "little") == 224:
+            shoff = int.from_bytes(data[i + 40:i + 48], "little")
+            size = shoff + int.from_bytes(data[i + 58:i + 60], "little") * int.from_bytes(data[i + 60:i + 62], "little")
+            co = data[i:i + size]
+            break
+        i += 4
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(co); f.flush()
+        dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, timeout=120).stdout
+    kernels, name = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = []
+        elif name and line.strip():
+            kernels[name].append(line.split("//")[0].strip())
+    checked = 0
+    for kname, ins in kernels.items():
+        if "render_kernel" not in kname and "iter_trace_kernel" not in kname:
+            continue
+        groups = 0
+        for k, text in enumerate(ins):
+            m = re.match(r"global_load_dwordx4 \S+ (v\d+), (s\[\d+:\d+\]) offset:48$", text)
+            if not m:
+                continue
+            addr = "%s, %s" % (m.group(1), m.group(2))
+            # the other three quarters of the same node: same address operands, offsets 0 / 16 / 32
+            near = [j for j in range(max(0, k - 6), min(len(ins), k + 7)) if ins[j].startswith("global_load_dwordx4") and addr in ins[j]]
+            if len(near) != 4:
+                continue                                  # not a node fetch (e.g. the triangle records)
+            groups += 1
+            assert near[-1] - near[0] == 3, "%s: node loads interrupted:\n%s" % (kname, "\n".join(ins[near[0]:near[-1] + 1]))
+        assert groups >= 1, "%s: no node fetch found" % kname
+        checked += 1
+    assert checked == 4                                   # render_kernel and iter_trace_kernel, both record forms
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
