@@ -102,6 +102,36 @@ __global__ void __launch_bounds__(256) NAME(const uint4 *__restrict__ tab, unsig
         } \
     out[gl] = acc + idx; \
 }
+// What interrupts the group: the same chase with ONE other instruction between the third and the fourth load.
+#define CHASE_GAP(NAME, GAP) \
+__global__ void __launch_bounds__(256) NAME(const uint4 *__restrict__ tab, unsigned mask, int active, int iters, unsigned *out) { \
+    const unsigned lane = threadIdx.x & 63u, gl = blockIdx.x * blockDim.x + threadIdx.x; \
+    unsigned idx = (gl * 2654435761u) & mask, acc = 0; \
+    if (lane < (unsigned)active) \
+        for (int i = 0; i < iters; i++) { \
+            const unsigned off = idx << 6; \
+            unsigned next, mix; \
+            asm volatile("v_mov_b32 v40, %2\n s_nop 1\n" \
+                         "global_load_dwordx4 v[44:47], v40, %3 offset:16\n" \
+                         "global_load_dwordx4 v[48:51], v40, %3\n" \
+                         "global_load_dwordx4 v[52:55], v40, %3 offset:48\n" \
+                         GAP "\n" \
+                         "global_load_dwordx4 v[56:59], v40, %3 offset:32\n" \
+                         "s_waitcnt vmcnt(0)\n v_mov_b32 %0, v48\n v_xor_b32 %1, v45, v53\n v_xor_b32 %1, %1, v57\n" \
+                         : "=&v"(next), "=&v"(mix) : "v"(off), "s"(tab) \
+                         : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", \
+                           "v56", "v57", "v58", "v59", "s40", "s41", "memory"); \
+            idx = next & mask; acc += mix; \
+        } \
+    out[gl] = acc + idx; \
+}
+CHASE_GAP(chase_gap_none, "")
+CHASE_GAP(chase_gap_nop, "s_nop 0")
+CHASE_GAP(chase_gap_valu, "v_mov_b32 v41, v40")
+CHASE_GAP(chase_gap_salu, "s_mov_b32 s40, 0")
+CHASE_GAP(chase_gap_exec, "s_mov_b64 s[40:41], exec")
+CHASE_GAP(chase_gap_wait, "s_waitcnt vmcnt(3)")
+
 CHASE_MOD(chase_nt, "nt")
 CHASE_MOD(chase_sc1, "sc1")
 CHASE_MOD(chase_sc01, "sc0 sc1")
@@ -155,6 +185,24 @@ int main(int argc, char **argv) {
                    "no s_nop %.3f ms (%.2f Gvisits/s, ratio %.3f)\n",
                    n * 64 >> 20, mixed == 2 ? "both halves of each line" : mixed ? "odd lanes in 8 KB" : "all lanes anywhere", active, ms[0], visits / ms[0] / 1e6,
                    ms[1], ms[1] / ms[0], ms[2], visits / ms[2] / 1e6, ms[2] / ms[0]);
+        }
+        if (only_ln < 0 || only_mixed == 4) {
+            typedef void (*K)(const uint4 *, unsigned, int, int, unsigned *);
+            const K ks[6] = {chase_gap_none, chase_gap_nop, chase_gap_valu, chase_gap_salu, chase_gap_exec, chase_gap_wait};
+            const char *names[6] = {"nothing", "s_nop 0", "v_mov_b32", "s_mov_b32", "s_mov_b64 from exec", "s_waitcnt vmcnt(3)"};
+            const int iters = ln >= 20 ? 400 : 2000;
+            for (int k = 0; k < 6; k++) {
+                float best = 0;
+                for (int rep = 0; rep < 2; rep++) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(ks[k], dim3(blocks), dim3(threads), 0, 0, tab, (unsigned)(n - 1), 64, iters, out);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+                    float t; CK(hipEventElapsedTime(&t, e0, e1));
+                    if (rep == 0 || t < best) best = t;
+                }
+                printf("table %4zu MB, between the third and fourth load %-20s: %.3f ms (%.2f Gvisits/s)\n", n * 64 >> 20, names[k], best,
+                       (double)blocks * (threads / 64) * 64 * iters / best / 1e6);
+            }
         }
         if (only_ln < 0 || only_mixed == 3) {
             typedef void (*K)(const uint4 *, unsigned, int, int, unsigned *);
