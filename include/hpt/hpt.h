@@ -148,7 +148,9 @@ int hpt_tonemap(hpt_ctx *ctx, const float *d_image, uint8_t *d_rgb8, int n_pixel
 /* Blocks until the context's stream is idle. */
 int hpt_synchronize(hpt_ctx *ctx);
 
-/* Counters of the last hpt_render / hpt_kernel_execute (synchronizes). */
+/* Counters of the last hpt_render / hpt_kernel_execute and device time per stage (types.h hpt_stats): render_kernel,
+ * fold_kernel, and the iterative calls' trace / shade / reconstruct kernels, each from HIP events around its launches
+ * (the reference has only the wall clock of one display() iteration, main.cpp:124-140).  Synchronizes. */
 int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats);
 
 #ifdef __cplusplus

@@ -91,16 +91,26 @@ typedef struct {
 #define HPT_HIT_MISS (-1)
 #define HPT_HIT_PRIMITIVE(k) (-(2 + (k)))
 
-/* counters of the last render call (rays = closest-hit queries) */
+/* Counters and per-stage device times of the last calls (rays = closest-hit queries).  Times are
+ * HIP-event times on the context's launch stream, in ms; a stage that has not run since hpt_create reads 0. */
 typedef struct {
     uint64_t rays_primary;
     uint64_t rays_bounce;
     uint64_t paths;
-    double   last_kernel_ms;   /* HIP-event time of the last render kernel, on its launch stream */
+    double   last_kernel_ms;   /* render_kernel launches of the last hpt_render / hpt_kernel_execute / hpt_render_sample, summed */
     int32_t  wide_nodes;       /* 64-B nodes resident on the device */
     int32_t  tree_depth;
     int32_t  grid_waves;       /* waves launched by the persistent kernel */
-    int32_t  reserved;
+    int32_t  launches;         /* render_kernel launches the last render was cut into (sample buffer) */
+    double   fold_ms;          /* fold_kernel launches of the same render, summed */
+    double   trace_ms;         /* iter_trace_kernel of the last hpt_first_bounce / hpt_bounce */
+    double   shade_ms;         /* iter_first_shade_kernel / iter_bounce_shade_kernel of the same call */
+    double   reconstruct_ms;   /* the last hpt_reconstruct_paths or hpt_reconstruct */
+    uint64_t lane_loads;       /* 16-B per-lane loads issued by the traversal and the shading of the counted rays (4 per node
+                                  visit, 5 per pair record / 3 per single record, 2 per shaded triangle hit): the unit of the
+                                  vector-L1 gather roofline.  Counted only by contexts created with
+                                  HPT_COUNT_LANE_LOADS=1 in the environment (a counting build of the kernel, 1.4 % slower);
+                                  0 otherwise */
 } hpt_stats;
 
 #ifdef __cplusplus

@@ -26,10 +26,14 @@ std::string g_create_error;
 constexpr int kMaxTreeDepth = 64;   // the reference's own bound: int todo[64], ray_kernel.cl:389
 constexpr int kBlock = 256;
 #define HPT_N_COUNTERS 16
+#define HPT_COUNTER_LOADS 15        // render_kernels.h: 16-B lane-loads
 
-struct Buffer {
-    void *ptr = nullptr;
-    size_t bytes = 0;
+
+// occupancy of a persistent kernel at a dynamic-LDS size: asked of the runtime once, not on every launch
+struct KernelShape {
+    const void *kernel;
+    size_t lds;
+    int blocks_per_cu;
 };
 
 }  // namespace
@@ -74,8 +78,16 @@ struct hpt_ctx {
     int32_t *d_hit_id = nullptr;
     float *d_hit_t = nullptr;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    // Per-stage timing (hpt_get_stats): HIP events on the launch stream.  A render records ev_render[3b], [3b+1], [3b+2]
+    // around the render_kernel and the fold_kernel of its b-th launch (the pool grows on demand); the iterative calls
+    // have fixed events.
+    std::vector<hipEvent_t> ev_render;
+    int timed_launches = 0;          // launches of the last render whose events were recorded
+    int launches = 0;                // launches of render_kernel by the last render
+    hipEvent_t ev_iter[3] = {nullptr, nullptr, nullptr};     // before trace, between trace and shade, after shade
+    hipEvent_t ev_recon[2] = {nullptr, nullptr};
+    bool timed_iter = false, timed_recon = false;
+    std::vector<KernelShape> shapes;
     int n_cu = 256;
     int grid_waves = 0;
     int shade_threshold = 24;        // scheduling knob of render_kernel (results do not depend on it): 24, up to 40 with the length of the
@@ -84,14 +96,16 @@ struct hpt_ctx {
     int tris_per_trip = 8;
     int node_repeat_min = 24;
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
+    int tail_chunks = 2;             // the last tail_chunks x waves x fetch_chunk work items of a launch are reserved 64 at a time (HPT_TAIL_CHUNKS)
     int fetch_threshold = 32;        // iter_trace_kernel's FETCH step threshold (HPT_FETCH_THRESHOLD overrides)
     int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
     size_t spill_bytes = 0;
     float *d_samples = nullptr;      // [iteration in batch][pixel slot][3] radiance samples of one launch
     size_t samples_bytes = 0;
-    size_t sample_budget_bytes = (size_t)8 << 30;   // HPT_SAMPLE_BUDGET_MB overrides; bounds iterations per launch
+    size_t sample_budget_bytes = (size_t)HPT_SAMPLE_BUDGET_DEFAULT_MB << 20;   // HPT_SAMPLE_BUDGET_MB overrides; bounds the paths per launch
     int blocks_per_cu_cap = 0;       // 0 = occupancy limit (HPT_BLOCKS_PER_CU overrides)
+    bool count_loads = false;        // HPT_COUNT_LANE_LOADS=1: renders run the counting instantiation of render_kernel (hpt_stats.lane_loads)
     void *d_iter = nullptr;          // per-pixel state of the iterative pipeline (one allocation), made by hpt_first_bounce
     IterState iter{};
     int iter_ready = 0;              // 1 after hpt_first_bounce
@@ -259,20 +273,42 @@ size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
     return (size_t)depth * block * sizeof(uint2);
 }
 
+// Dynamic LDS any kernel here may ask for: a full-depth stack (kMaxTreeDepth entries of 8 B for 256 lanes).  Set once
+// per kernel (the attribute is per function, so every context sets the same value), with the occupancy at the
+// launch's actual LDS size cached beside it: neither is asked of the runtime again on later launches.
+constexpr size_t kMaxDynamicLds = (size_t)kMaxTreeDepth * kBlock * sizeof(uint2);
+
+int kernel_shape(hpt_ctx *ctx, const void *kernel, size_t lds, int &blocks_per_cu) {
+    bool attribute_set = false;
+    for (const KernelShape &k : ctx->shapes) {
+        if (k.kernel != kernel) continue;
+        attribute_set = true;
+        if (k.lds == lds) { blocks_per_cu = k.blocks_per_cu; return HPT_OK; }
+    }
+    if (!attribute_set)
+        HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynamicLds));
+    int per_cu = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds));
+    ctx->shapes.push_back({kernel, lds, per_cu});
+    blocks_per_cu = per_cu;
+    return HPT_OK;
+}
+
 // Launch shape of a persistent traversal kernel (render_kernel, iter_trace_kernel): LDS for the capped
 // traversal stack, as many blocks as stay resident, HBM overflow of the stack sized for that grid.
 int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t &lds, long &blocks_max) {
     const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
     const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
     lds = (size_t)cap * kBlock * sizeof(uint2);
-    HIP_TRY(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
-    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds));
+    int rc = kernel_shape(ctx, kernel, lds, per_cu);
+    if (rc) return rc;
     if (per_cu < 1) return fail(ctx, HPT_ERR_INVALID, "render kernel does not fit: %zu B of LDS per block", lds);
     if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
     blocks_max = (long)per_cu * ctx->n_cu;
     p.stack_cap = cap;
-    size_t spill_need = (size_t)(depth - cap) * (size_t)(blocks_max * kBlock) * sizeof(uint2);
+    const size_t per_block = (size_t)(depth - cap) * kBlock * sizeof(uint2);
+    const size_t spill_need = (size_t)blocks_max * per_block;
     if (spill_need > ctx->spill_bytes) {
         if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
         HIP_ALLOC(ctx, &ctx->d_spill, spill_need);
@@ -282,8 +318,21 @@ int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t
     return HPT_OK;
 }
 
-// One render = one or more launches of render_kernel (each over a batch of iterations whose samples fit the
-// sample buffer) each followed by fold_kernel.
+// events [3b], [3b+1], [3b+2] of the render's b-th launch
+int render_events(hpt_ctx *ctx, int launch) {
+    while ((int)ctx->ev_render.size() < 3 * (launch + 1)) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_render.push_back(e);
+    }
+    return HPT_OK;
+}
+
+// One render = one or more launches of render_kernel, each followed by fold_kernel.  A launch covers a range of the
+// shard's pixel slots times a range of iterations whose samples fit the sample buffer: the whole shard and every
+// iteration when that fits; else all iterations of as many 8x8 tiles as fit (a pixel is then folded once); else,
+// for very long renders, one tile range and several iteration batches.  The split changes nothing in the image:
+// fold_kernel folds a pixel's samples in iteration order whatever launch made them.
 int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int raw) {
     RenderParams p;
     int rc = fill_params(ctx, p, d_image, spp_begin, spp_end, raw);
@@ -291,16 +340,10 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
         return fail(ctx, HPT_ERR_INVALID, "triangles need materials[0] (ray_kernel.cl:752-754): call hpt_set_scene");
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
-    ctx->timed = false;
-    if (p.n_slots == 0) return HPT_OK;
+    ctx->timed_launches = 0; ctx->launches = 0;
+    const uint32_t shard_slots = p.n_slots;
+    if (shard_slots == 0) return HPT_OK;
 
-    // iterations per launch: bounded by the sample buffer budget and by 32-bit work indices
-    const size_t bytes_per_iteration = (size_t)p.n_slots * 3 * sizeof(float);
-    long batch_max = (long)(ctx->sample_budget_bytes / bytes_per_iteration);
-    // 32-bit work indices, with headroom for the counter's overshoot (one chunk of <= 4096 per wave, < 2^16 waves)
-    const long idx_max = (long)(0xF0000000u / p.n_slots);
-    if (batch_max > idx_max) batch_max = idx_max;
-    if (batch_max < 1) batch_max = 1;
     // sample shards: this rank renders the iterations s = sample_rank + sample_world * l of the range, and folds
     // them as ITS running mean (count l + 1); hpt_kernel_execute (raw) names its iteration itself
     const int G = raw ? 1 : ctx->sample_world, r = raw ? 0 : ctx->sample_rank;
@@ -308,42 +351,70 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     const int l_begin = locals_below(spp_begin), l_end = locals_below(spp_end);
     const int total = l_end - l_begin;
     if (total <= 0) return HPT_OK;
-    const int batch_alloc = total < batch_max ? total : (int)batch_max;
-    const size_t samples_need = bytes_per_iteration * (size_t)batch_alloc;
-    if (samples_need > ctx->samples_bytes) {
-        if (ctx->d_samples) { HIP_TRY(ctx, hipFree(ctx->d_samples)); ctx->d_samples = nullptr; ctx->samples_bytes = 0; }
-        HIP_ALLOC(ctx, &ctx->d_samples, samples_need);
-        ctx->samples_bytes = samples_need;
-    }
-    p.samples = ctx->d_samples;
 
     size_t lds; long blocks_max;
-    const void *kernel = ctx->singles ? (const void *)render_kernel<true> : (const void *)render_kernel<false>;
-    if ((rc = prepare_persistent(ctx, kernel, p, lds, blocks_max))) return rc;
+    typedef void (*render_fn)(const RenderParams);
+    const render_fn fn = ctx->count_loads ? (ctx->singles ? render_kernel<true, true> : render_kernel<false, true>)
+                                          : (ctx->singles ? render_kernel<true, false> : render_kernel<false, false>);
+    if ((rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max))) return rc;
 
-    const bool single = total <= batch_alloc;     // then the events bracket render_kernel alone
-    if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int base = l_begin; base < l_end; base += batch_alloc) {
-        p.spp_base = base;
-        p.spp_first = r + G * base; p.spp_stride = G;
-        p.batch = (l_end - base) < batch_alloc ? (l_end - base) : batch_alloc;
-        p.n_work = p.n_slots * (uint32_t)p.batch;
-        long blocks = blocks_max;
-        long need = ((long)p.n_work + kBlock - 1) / kBlock;
-        if (blocks > need) blocks = need;
-        ctx->grid_waves = (int)(blocks * (kBlock / 64));
-        p.spill_stride = (uint32_t)(blocks * kBlock);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
-        if (single) HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        if (ctx->singles) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
-        else hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
-        HIP_TRY(ctx, hipGetLastError());
-        if (single) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        hipLaunchKernelGGL(fold_kernel, dim3((p.n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, p);
-        HIP_TRY(ctx, hipGetLastError());
+    // paths (= 12-B samples) per launch: the sample buffer, and 32-bit work indices with headroom for the work
+    // counter's overshoot (one chunk of <= 4096 per wave, < 2^16 waves)
+    const size_t sample_bytes = 3 * sizeof(float);
+    size_t capacity = ctx->sample_budget_bytes / sample_bytes;
+    if (capacity > 0xF0000000u) capacity = 0xF0000000u;
+    if (capacity < 64) capacity = 64;                     // (a budget below one tile: one tile, one iteration at a time)
+    uint32_t range_slots; int batch;
+    if ((size_t)shard_slots * (size_t)total <= capacity) { range_slots = shard_slots; batch = total; }
+    else if ((capacity / (size_t)total) >= 64) { range_slots = (uint32_t)((capacity / (size_t)total) & ~(size_t)63); batch = total; }
+    else { range_slots = 64; batch = (int)(capacity / 64); }
+    if (range_slots > shard_slots) range_slots = shard_slots;
+
+    {
+        size_t samples_need = (size_t)range_slots * (size_t)batch * sample_bytes;
+        while (samples_need > ctx->samples_bytes) {
+            if (ctx->d_samples) { HIP_TRY(ctx, hipFree(ctx->d_samples)); ctx->d_samples = nullptr; ctx->samples_bytes = 0; }
+            hipError_t e = hipMalloc((void **)&ctx->d_samples, samples_need);
+            if (e == hipSuccess) { ctx->samples_bytes = samples_need; break; }
+            (void)hipGetLastError();
+            if (e != hipErrorOutOfMemory) return fail(ctx, HPT_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e));
+            // a busy device: halve the launch (fewer tiles, then fewer iterations) before giving up
+            if (range_slots > 64) range_slots = ((range_slots / 2) + 63) & ~63u;
+            else if (batch > 1) batch = (batch + 1) / 2;
+            else return fail(ctx, HPT_ERR_NOMEM, "out of device memory allocating %zu bytes of samples", samples_need);
+            samples_need = (size_t)range_slots * (size_t)batch * sample_bytes;
+        }
+        p.samples = ctx->d_samples;
     }
-    if (!single) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->timed = true;
+
+    int launch = 0;
+    for (uint32_t slot0 = 0; slot0 < shard_slots; slot0 += range_slots) {
+        p.slot_base = slot0;
+        p.n_slots = (shard_slots - slot0) < range_slots ? (shard_slots - slot0) : range_slots;
+        for (int base = l_begin; base < l_end; base += batch, launch++) {
+            p.spp_base = base;
+            p.spp_first = r + G * base; p.spp_stride = G;
+            p.batch = (l_end - base) < batch ? (l_end - base) : batch;
+            p.n_work = p.n_slots * (uint32_t)p.batch;
+            long blocks = blocks_max;
+            long need = ((long)p.n_work + kBlock - 1) / kBlock;
+            if (blocks > need) blocks = need;
+            ctx->grid_waves = (int)(blocks * (kBlock / 64));
+            p.spill_stride = (uint32_t)(blocks * kBlock);
+            p.tail_items = (uint32_t)ctx->tail_chunks * (uint32_t)ctx->grid_waves * (uint32_t)p.fetch_chunk;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
+            if ((rc = render_events(ctx, launch))) return rc;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch], ctx->stream));
+            hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch + 1], ctx->stream));
+            hipLaunchKernelGGL(fold_kernel, dim3((p.n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, p);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch + 2], ctx->stream));
+            ctx->timed_launches = launch + 1;
+        }
+    }
+    ctx->launches = launch;
     return HPT_OK;
 }
 
@@ -382,9 +453,11 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
     if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->fetch_chunk = v; }
+    if (const char *e = getenv("HPT_TAIL_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->tail_chunks = v; }
     if (const char *e = getenv("HPT_FETCH_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->fetch_threshold = v; }
     if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
+    if (const char *e = getenv("HPT_COUNT_LANE_LOADS")) ctx->count_loads = atoi(e) != 0;
     size_t img = (size_t)width * height * 3 * sizeof(float);
     if ((e = hipMalloc((void **)&ctx->d_work, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_counters, HPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
@@ -393,8 +466,15 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if ((e = hipMalloc((void **)&ctx->d_hit_id, (size_t)width * height * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_hit_t, (size_t)width * height * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    for (hipEvent_t *ev : {&ctx->ev_iter[0], &ctx->ev_iter[1], &ctx->ev_iter[2], &ctx->ev_recon[0], &ctx->ev_recon[1]})
+        if ((e = hipEventCreate(ev)) != hipSuccess) return bail("hipEventCreate", e);
+    ctx->ev_render.reserve(96);
+    for (int k = 0; k < 3; k++) {
+        hipEvent_t ev = nullptr;
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+        ctx->ev_render.push_back(ev);
+    }
+    ctx->shapes.reserve(16);
     *out = ctx;
     return HPT_OK;
 }
@@ -406,8 +486,9 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);
     (void)hipFree(ctx->d_iter); (void)hipFree(ctx->d_pairs);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t ev : ctx->ev_render) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->ev_iter) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->ev_recon) if (ev) (void)hipEventDestroy(ev);
     delete ctx;
     return HPT_OK;
 }
@@ -442,7 +523,7 @@ int hpt_upload_triangles(hpt_ctx *ctx, const hpt_triangle *triangles, int n_tria
     ctx->n_tris = n_triangles;
     ctx->h_tris.assign(triangles, triangles + n_triangles);
     ctx->pairs_dirty = true;
-    return HPT_OK;
+    return ensure_pairs(ctx);           // builds the traversal's records once tree and triangles are both here
 }
 
 // Depth-first reference arrays -> 64-B two-child nodes.  Interior node k of the
@@ -498,6 +579,9 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
         todo.push_back({k + 1, it.depth + 1});
     }
 
+    // the NODE step addresses nodes by a 32-bit byte offset (render_kernels.h trav_node_steps)
+    if (n_wide >= (1 << 25)) return fail(ctx, HPT_ERR_BVH, "%d interior nodes: at most 2^25-1 (32-bit node byte offsets)", n_wide);
+
     // pass 2: fill
     std::vector<WideNode> wide(n_wide);
     for (int k = 0; k < n_nodes; k++) {
@@ -520,7 +604,7 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
     ctx->h_wide.swap(wide);                              // uploaded by ensure_pairs() with leaf references re-pointed
     ctx->n_wide = n_wide;
     ctx->tree_depth = depth_max;
-    return HPT_OK;
+    return ensure_pairs(ctx);           // (a no-op until the triangles the leaves name are uploaded too)
 }
 
 int hpt_set_scene(hpt_ctx *ctx, const hpt_primitive *primitives, int n_primitives,
@@ -580,9 +664,13 @@ int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_p
     if (rc) return rc;
     if (!d_image || !d_sample || n_pixels < 0) return fail(ctx, HPT_ERR_INVALID, "bad reconstruct arguments");
     long n = 3L * n_pixels;
+    ctx->timed_recon = false;
     if (n == 0) return HPT_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_recon[0], ctx->stream));
     hipLaunchKernelGGL(reconstruct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_image, d_sample, n, iterations);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_recon[1], ctx->stream));
+    ctx->timed_recon = true;
     return HPT_OK;
 }
 
@@ -608,9 +696,11 @@ static int iter_trace(hpt_ctx *ctx, RenderParams &p, int first) {
     if (blocks > need) blocks = need;
     p.spill_stride = (uint32_t)(blocks * kBlock);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_iter[0], ctx->stream));
     if (ctx->singles) hipLaunchKernelGGL(iter_trace_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
     else hipLaunchKernelGGL(iter_trace_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_iter[1], ctx->stream));
     return HPT_OK;
 }
 
@@ -634,12 +724,14 @@ int hpt_first_bounce(hpt_ctx *ctx) {
     // pixels outside the shard keep zeroed state (count 0, no contribution)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_iter, 0, npx * kIterBytesPerPixel, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, HPT_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
-    ctx->timed = false;
+    ctx->timed_launches = 0; ctx->launches = 0; ctx->timed_iter = false; ctx->timed_recon = false;
     ctx->iter_ready = 1; ctx->iter_pending = 0;
     if (blocks == 0) return HPT_OK;
     if ((rc = iter_trace(ctx, p, 1))) return rc;
     hipLaunchKernelGGL(iter_first_shade_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_iter[2], ctx->stream));
+    ctx->timed_iter = true;
     return HPT_OK;
 }
 
@@ -651,10 +743,13 @@ int hpt_bounce(hpt_ctx *ctx) {
     RenderParams p; unsigned blocks;
     if ((rc = iter_launch_params(ctx, p, blocks))) return rc;
     ctx->iter_pending = 1;
+    ctx->timed_iter = false;
     if (blocks == 0) return HPT_OK;
     if ((rc = iter_trace(ctx, p, 0))) return rc;
     hipLaunchKernelGGL(iter_bounce_shade_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_iter[2], ctx->stream));
+    ctx->timed_iter = true;
     return HPT_OK;
 }
 
@@ -666,9 +761,13 @@ int hpt_reconstruct_paths(hpt_ctx *ctx, float *d_image) {
     RenderParams p; unsigned blocks;
     if ((rc = iter_launch_params(ctx, p, blocks))) return rc;
     ctx->iter_pending = 0;
+    ctx->timed_recon = false;
     if (blocks == 0) return HPT_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_recon[0], ctx->stream));
     hipLaunchKernelGGL(iter_reconstruct_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, p, ctx->iter, d_image);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_recon[1], ctx->stream));
+    ctx->timed_recon = true;
     return HPT_OK;
 }
 
@@ -704,7 +803,8 @@ int hpt_primary_hits(hpt_ctx *ctx, int iteration, int32_t *hit_id, float *t) {
     if ((rc = fill_params(ctx, p, nullptr, iteration, iteration + 1, 1))) return rc;
     int npx = ctx->width * ctx->height;
     size_t lds = stack_lds_bytes(ctx, kBlock);
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)primary_hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int unused_per_cu = 0;
+    if ((rc = kernel_shape(ctx, (const void *)primary_hits_kernel, lds, unused_per_cu))) return rc;
     hipLaunchKernelGGL(primary_hits_kernel, dim3((unsigned)((npx + kBlock - 1) / kBlock)), dim3(kBlock), lds, ctx->stream, p, iteration);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(hit_id, ctx->d_hit_id, (size_t)npx * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -774,6 +874,7 @@ int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats) {
     unsigned long long c[HPT_N_COUNTERS];
     HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
     stats->rays_primary = c[0]; stats->rays_bounce = c[1]; stats->paths = c[2];
+    stats->lane_loads = c[HPT_COUNTER_LOADS];
 #ifdef HPT_PROFILE_STEPS
     fprintf(stderr, "[hpt profile] trips S/T/N %llu %llu %llu  lane-active S/T/N %llu %llu %llu  util %.3f %.3f %.3f\n",
             c[3] / 64, c[4] / 64, c[5] / 64, c[6], c[7], c[8], c[3] ? (double)c[6] / c[3] : 0.0, c[4] ? (double)c[7] / c[4] : 0.0,
@@ -783,12 +884,27 @@ int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats) {
     fprintf(stderr, "[hpt profile] of all lane-trips: waiting for SHADE %.3f, out of work %.3f\n",
             (double)c[9] / (double)(c[3] + c[4] + c[5]), (double)c[10] / (double)(c[3] + c[4] + c[5]));
 #endif
-    if (ctx->timed) {
+    for (int b = 0; b < ctx->timed_launches; b++) {
         float ms = 0;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-        stats->last_kernel_ms = ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_render[3 * b], ctx->ev_render[3 * b + 1]));
+        stats->last_kernel_ms += ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_render[3 * b + 1], ctx->ev_render[3 * b + 2]));
+        stats->fold_ms += ms;
+    }
+    if (ctx->timed_iter) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_iter[0], ctx->ev_iter[1]));
+        stats->trace_ms = ms;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_iter[1], ctx->ev_iter[2]));
+        stats->shade_ms = ms;
+    }
+    if (ctx->timed_recon) {
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_recon[0], ctx->ev_recon[1]));
+        stats->reconstruct_ms = ms;
     }
     stats->wide_nodes = ctx->n_wide; stats->tree_depth = ctx->tree_depth; stats->grid_waves = ctx->grid_waves;
+    stats->launches = ctx->launches;
     return HPT_OK;
 }
 

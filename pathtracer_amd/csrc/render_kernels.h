@@ -43,7 +43,7 @@ struct RenderParams {
     int32_t *hit_id;                 // primary_hits only
     float *hit_t;
     unsigned int *work_counter;
-    unsigned long long *counters;    // [0] primary rays [1] bounce rays [2] paths
+    unsigned long long *counters;    // [0] primary rays [1] bounce rays [2] paths [15] 16-B lane-loads of the traversal and shading
     hpt_camera cam;
     float root_lo[3], root_hi[3];
     int32_t root_ref;                // HPT_REF_DONE when there is no tree
@@ -64,11 +64,14 @@ struct RenderParams {
     uint2 *spill;                    // [entry - stack_cap][grid lane], HBM; only touched by rays deeper than stack_cap
     uint32_t spill_stride;           // lanes in the grid
     float *samples;                  // [batch sample][slot][3]: one radiance sample per (pixel, iteration) of this launch
-    uint32_t n_slots;                // pixel slots of this shard = local tiles * 64
+    uint32_t n_slots;                // pixel slots of this launch: a range of this shard's slots (local tiles * 64 of them)
+    uint32_t slot_base;              // first slot of the range (a multiple of 64): launches can cover a frame in slot ranges, so the
+                                     // sample buffer bounds the work per launch, not the frame size
     int32_t batch;                   // samples per pixel in this launch: the rank's samples spp_base .. spp_base + batch - 1
     int32_t spp_base;                // (fold_kernel's running-mean count), which are the frame's iterations
     int32_t spp_first, spp_stride;   // spp_first + k * spp_stride (sample shards: stride = ranks; otherwise 1)
     int32_t fetch_chunk;             // work items a wave reserves per atomic, <= 4096 (scheduling only)
+    uint32_t tail_items;             // the last tail_items of a launch are reserved 64 at a time (scheduling only)
     int32_t singles;                 // record form of this tree (chosen per tree by the host, see HPT_SINGLE_*)
     int32_t fetch_threshold;         // iter_trace_kernel: lanes that must want a new ray before the wave fetches (scheduling only)
 };
@@ -534,10 +537,15 @@ __device__ __forceinline__ void trav_pop(const RenderParams &p, Trav &s, uint2 *
 // TRI step: up to tris_per_trip triangles of the current leaf (or of the next one, when the pop lands on a
 // leaf), two per iteration from one pair record.  A lane is in the TRI state exactly when cur < 0, so the state
 // is re-read from cur, not carried.  ~cur = (next pair << 6) | (triangles left - 1).
-template <bool SINGLES>
-__device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
+// COUNT (the counting instantiation of render_kernel, HPT_COUNT_LANE_LOADS=1): loads = the wave's count of 16-B
+// lane-loads (a scalar: active lanes x loads of the group, from the ballots the step takes anyway); n_in = lanes in
+// the TRI state at entry.  The count costs 1.4 % at C3, so the default kernel does not carry it.
+template <bool SINGLES, bool COUNT>
+__device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill,
+                                               int n_in, unsigned long long &loads) {
     if (SINGLES) {
         // one triangle per 48-B record: ~cur = (next record << 6) | (triangles left - 1)
+        if (COUNT) loads += (unsigned)(n_in * HPT_SINGLE_FLOAT4S);
         for (int k = 0; k < p.tris_per_trip; k++) {
             if (s.cur < 0) {
                 const int packed = ~s.cur, rec = packed >> 6;
@@ -551,10 +559,13 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
                 if ((packed & 63) == 0) trav_pop(p, s, stack, stride, spill);
                 else s.cur = ~(packed + 63);                      // next record, one fewer left
             }
-            if (hpt_ballot(s.cur < 0) == 0ull) break;
+            const unsigned long long left_in = hpt_ballot(s.cur < 0);
+            if (left_in == 0ull) break;
+            if (COUNT && k + 1 < p.tris_per_trip) loads += (unsigned)(__popcll(left_in) * HPT_SINGLE_FLOAT4S);
         }
         return;
     }
+    if (COUNT) loads += (unsigned)(n_in * HPT_PAIR_FLOAT4S);
     for (int k = 0; k < p.tris_per_trip; k += 2) {
         if (s.cur < 0) {
             const int packed = ~s.cur, pair = packed >> 6, left = (packed & 63) + 1;
@@ -575,13 +586,18 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
             if (left <= 2) trav_pop(p, s, stack, stride, spill);
             else s.cur = ~(packed + 64 - 2);                  // next pair, two fewer left
         }
-        if (hpt_ballot(s.cur < 0) == 0ull) break;
+        const unsigned long long left_in = hpt_ballot(s.cur < 0);
+        if (left_in == 0ull) break;
+        if (COUNT && k + 2 < p.tris_per_trip) loads += (unsigned)(__popcll(left_in) * HPT_PAIR_FLOAT4S);
     }
 }
 
 // NODE step: both children per visit; the wave stays here, without a full re-vote, while at least
 // node_repeat_min lanes still have an interior node to test.
-__device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill) {
+template <bool COUNT>
+__device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill,
+                                                int n_in, unsigned long long &loads) {
+    if (COUNT) loads += (unsigned)(n_in * 4);
     for (;;) {
 #ifdef HPT_PROFILE_STEPS
         {   // development build: how many NODE iterations have all their lanes at ONE node (a scalar load would do)
@@ -621,7 +637,9 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
             } else if (hF) s.cur = refF;
             else trav_pop(p, s, stack, stride, spill);
         }
-        if (__popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE)) < p.node_repeat_min) break;
+        const int again = __popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE));
+        if (again < p.node_repeat_min) break;
+        if (COUNT) loads += (unsigned)(again * 4);
     }
 }
 
@@ -670,11 +688,12 @@ __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o,
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 6
 #endif
-template <bool SINGLES>
+template <bool SINGLES, bool COUNT>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;   // per WAVE (from ballots: scalar registers, not three per lane)
+    unsigned long long n_loads = 0;                      // per WAVE: 16-B lane-loads issued (nodes, triangle records, hit triangles' edges)
 #ifdef HPT_PROFILE_STEPS
     unsigned long long prof_it[3] = {0, 0, 0}, prof_act[3] = {0, 0, 0};
     unsigned long long prof_waitS = 0, prof_idle = 0;     // per lane: trips spent waiting for SHADE / without work
@@ -715,6 +734,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                 bool ended = false;
                 n_primary += (unsigned)__popcll(hpt_ballot(wantS && b == 0));
                 n_bounce += (unsigned)__popcll(hpt_ballot(wantS && b > 0));
+                if (COUNT) n_loads += 2u * (unsigned)__popcll(hpt_ballot(wantS && b >= 0 && tv.hit >= 0));   // e1, e2 of the hit triangle
                 if (wantS && b >= 0) {   // a ray has just finished: one bounce of the path loop
                     r.o = mk3(tv.oxy.x, tv.oxy.y, tv.ozix.x); r.d = tv.rd;
                     bool go_on = shade_bounce(p, tv.hit, tv.t, r, key, ctr, b, color, weight);
@@ -738,20 +758,24 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                     if (chunk_next >= chunk_end) {
                         // after the first miss a wave never touches the counter again, so the counter overshoots
                         // n_work by at most waves * fetch_chunk (the host keeps that much headroom below 2^32)
+                        // Near the end of the launch (this wave's last reservation began inside the final
+                        // tail_items) a wave takes 64 items at a time instead of fetch_chunk: the last waves to
+                        // reserve then hold one path per lane, not four, and the grid drains sooner.
+                        const unsigned take = (p.n_work - chunk_end) <= p.tail_items ? 64u : (unsigned)p.fetch_chunk;
                         unsigned at = 0xffffffffu;
-                        if (!exhausted && lane == 0u) at = atomicAdd(p.work_counter, (unsigned)p.fetch_chunk);
+                        if (!exhausted && lane == 0u) at = atomicAdd(p.work_counter, take);
                         at = __builtin_amdgcn_readfirstlane(at);
                         if (at >= p.n_work) { exhausted = true; if (want) tv.cur = HPT_REF_IDLE; break; }
                         chunk_next = at;
-                        chunk_end = (p.n_work - at) < (unsigned)p.fetch_chunk ? p.n_work : at + (unsigned)p.fetch_chunk;
+                        chunk_end = (p.n_work - at) < take ? p.n_work : at + take;
                     }
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
                     const unsigned avail = chunk_end - chunk_next;
                     if (want && rank < avail) {
                         const unsigned work = chunk_next + rank;
                         const unsigned group = work >> 6, tile = group / (unsigned)p.batch, sl = group - tile * (unsigned)p.batch;
-                        const unsigned slot = tile * 64u + (work & 63u);
-                        gid = work_to_pixel(p, slot);
+                        const unsigned slot = tile * 64u + (work & 63u);       // within this launch's slot range
+                        gid = work_to_pixel(p, p.slot_base + slot);
                         if (gid >= 0) { s = p.spp_first + (int)sl * p.spp_stride; out_idx = sl * p.n_slots + slot; want = false; }
                     }
                     const unsigned cnt = (unsigned)__popcll(need);
@@ -769,15 +793,16 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                 }
             }
         } else if (nT > nN) {
-            trav_tri_steps<SINGLES>(p, tv, stack, stride, spill);
+            trav_tri_steps<SINGLES, COUNT>(p, tv, stack, stride, spill, nT, n_loads);
         } else {
-            trav_node_steps(p, tv, stack, stride, spill);
+            trav_node_steps<COUNT>(p, tv, stack, stride, spill, nN, n_loads);
         }
     }
     if (lane == 0u) {
         atomicAdd(p.counters + 0, (unsigned long long)n_primary);
         atomicAdd(p.counters + 1, (unsigned long long)n_bounce);
         atomicAdd(p.counters + 2, (unsigned long long)n_paths);
+        if (COUNT) atomicAdd(p.counters + 15, n_loads);
     }
 #ifdef HPT_PROFILE_STEPS
     for (int k = 0; k < 3; k++) { atomicAdd(p.counters + 3 + k, prof_it[k]); atomicAdd(p.counters + 6 + k, prof_act[k]); }
@@ -791,7 +816,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
 __global__ void __launch_bounds__(256) fold_kernel(const RenderParams p) {
     unsigned slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= p.n_slots) return;
-    int gid = work_to_pixel(p, slot);
+    int gid = work_to_pixel(p, p.slot_base + slot);
     if (gid < 0) return;
     float *px = p.image + 3 * (size_t)gid;
     f3 mean = mk3(0, 0, 0);
@@ -853,6 +878,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const Re
     chunk = chunk < 64u ? 64u : (chunk > 1024u ? 1024u : chunk);
     unsigned chunk_next = 0, chunk_end = 0;              // wave-uniform
     unsigned traced = 0;
+    unsigned long long n_loads = 0;                      // (not counted here)
     int gid = -1;
     Trav tv;
     tv.oxy = hpt_v2f{0, 0}; tv.ozix = hpt_v2f{0, 0}; tv.iyz = hpt_v2f{0, 0}; tv.rd = mk3(0, 0, 1);
@@ -904,9 +930,9 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const Re
                 trav_start(p, tv, o, d);
             }
         } else if (nT > nN) {
-            trav_tri_steps<SINGLES>(p, tv, stack, stride, spill);
+            trav_tri_steps<SINGLES, false>(p, tv, stack, stride, spill, nT, n_loads);
         } else {
-            trav_node_steps(p, tv, stack, stride, spill);
+            trav_node_steps<false>(p, tv, stack, stride, spill, nN, n_loads);
         }
     }
     __shared__ unsigned block_rays;

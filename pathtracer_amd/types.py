@@ -25,10 +25,12 @@ class Stats(C.Structure):
     """hpt_stats"""
     _fields_ = [("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("paths", C.c_uint64),
                 ("last_kernel_ms", C.c_double), ("wide_nodes", C.c_int32), ("tree_depth", C.c_int32),
-                ("grid_waves", C.c_int32), ("reserved", C.c_int32)]
+                ("grid_waves", C.c_int32), ("launches", C.c_int32),
+                ("fold_ms", C.c_double), ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("reconstruct_ms", C.c_double),
+                ("lane_loads", C.c_uint64)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 HIT_MISS = -1

@@ -499,6 +499,182 @@ def test_full_size_properties_c3():
         assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0
 
 
+@pytest.mark.parametrize("env", [dict(), dict(HPT_SHADE_THRESHOLD="1"), dict(HPT_SHADE_THRESHOLD="64", HPT_SAMPLE_BUDGET_MB="1")])
+def test_c5_glossy_render_bit_exact(env, monkeypatch):
+    """Config C5 (glossy sponza-class geometry, specular + IOR triangle material, 64 mirror and 64 glass sphere
+    primitives: 129 analytic tests per ray) through hpt_render -- the path the bench times -- at reduced resolution,
+    several iterations, continued across calls: Fresnel coin, mirror / refraction / total internal reflection,
+    Russian roulette (pathtracer_kernel.cl:804-845; primitives ray_kernel.cl:524-602).  Run with the SHADE
+    threshold the backend derives from the primitive count (40), with 1 and 64 forced, and with a sample buffer
+    that cuts the render into launches over tile ranges."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s, bvh, o = get_scene("glossy", width=160, height=90)
+    assert len(s["primitives"]) == 129
+    be = backend_for(s, bvh)
+    d = dev_image(be)
+    be.render(0, 3, d.data_ptr()); be.render(3, 10, d.data_ptr()); be.synchronize()
+    st = be.stats()
+    want, cnt = o.render(0, 10)
+    assert mismatch(d.cpu().numpy(), want) == 0
+    _, cnt2 = o.render(3, 10, image=o.render(0, 3)[0])
+    assert (st["rays_primary"], st["rays_bounce"], st["paths"]) == (cnt2["rays_primary"], cnt2["rays_bounce"], cnt2["paths"])
+    if "HPT_SAMPLE_BUDGET_MB" in env:
+        assert st["launches"] > 1
+    # the glass and mirror spheres are really hit, and paths really run long (RR region b > 3)
+    hit, _ = be.primary_hits(0)
+    assert (hit <= -3).sum() > 20 and cnt["rays_bounce"] > 2 * cnt["rays_primary"]
+
+
+def test_c5_glossy_both_shard_modes():
+    """C5 under the two multi-GPU partitions of SURVEY.md 8e: tile shards reassemble bit for bit; each sample
+    shard equals the oracle's samples of its iterations folded as its own running mean, and the weighted sum is
+    the frame within 1e-5."""
+    from pathtracer_amd import dist as pd
+    s, bvh, o = get_scene("glossy", width=96, height=54)
+    w, h, n_it = 96, 54, 6
+    want = o.render(0, n_it)[0].reshape(-1)
+    be = backend_for(s, bvh)
+    out = dev_image(be)
+    slabs = []
+    for r in range(4):
+        be.set_shard(r, 4)
+        d = dev_image(be)
+        be.render(0, n_it, d.data_ptr())
+        slab = torch.empty(be.slab_floats(), dtype=torch.float32, device="cuda")
+        be.pack_tiles(d.data_ptr(), slab.data_ptr()); be.synchronize()
+        slabs.append(slab)
+    be.unpack_tiles(torch.cat(slabs).data_ptr(), out.data_ptr()); be.synchronize()
+    assert mismatch(out.cpu().numpy(), want) == 0
+    be.set_shard(0, 1)
+    samples = [o.kernel_execute(k)[0].reshape(-1) for k in range(n_it)]
+    frame = np.zeros(w * h * 3, np.float32)
+    for r in range(2):
+        be.set_sample_shard(r, 2)
+        d = dev_image(be)
+        be.render(0, n_it, d.data_ptr()); be.synchronize()
+        mine = samples[r::2]
+        mean = mine[0].copy()
+        for k in range(1, len(mine)):
+            it = np.float32(k + 1)
+            mean = (np.float32(1) / it) * mine[k] + (np.float32(k) / it) * mean
+        assert mismatch(d.cpu().numpy(), mean) == 0, r
+        frame += np.float32(pd.sample_shard_count(0, n_it, r, 2) / n_it) * d.cpu().numpy()
+    assert np.allclose(frame, want, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_properties_c5():
+    """BASELINE config C5 at full size (glossy, 129 primitives, 3840x2160), two samples per pixel through hpt_render:
+    (1) a split spp range continues the same running mean, (2) eight tile shards reassemble to the unsharded image,
+    (3) the two sample shards' weighted sum is the frame within 1e-5, (4) two pixel rows equal the oracle bit for
+    bit, (5) counters: one primary ray per path, more bounce rays than paths."""
+    s, bvh, o = get_scene("glossy")
+    be = backend_for(s, bvh)
+    w, h = s["width"], s["height"]
+    assert (w, h) == (3840, 2160)
+    a = dev_image(be)
+    be.render(0, 2, a.data_ptr()); be.synchronize()
+    st = be.stats()
+    assert st["paths"] == 2 * w * h and st["rays_primary"] == st["paths"] and st["rays_bounce"] > st["paths"]
+    b = dev_image(be)
+    be.render(0, 1, b.data_ptr()); be.render(1, 2, b.data_ptr()); be.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    c = dev_image(be)
+    slabs = []
+    for r in range(8):
+        be.set_shard(r, 8)
+        d = dev_image(be)
+        be.render(0, 2, d.data_ptr())
+        slab = torch.empty(be.slab_floats(), dtype=torch.float32, device="cuda")
+        be.pack_tiles(d.data_ptr(), slab.data_ptr()); be.synchronize()
+        slabs.append(slab)
+    be.unpack_tiles(torch.cat(slabs).data_ptr(), c.data_ptr()); be.synchronize()
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    del slabs, c, b
+    be.set_shard(0, 1)
+    frame = torch.zeros_like(a)
+    for r in range(2):
+        be.set_sample_shard(r, 2)
+        d = dev_image(be)
+        be.render(0, 2, d.data_ptr()); be.synchronize()
+        frame += 0.5 * d
+    assert torch.allclose(frame, a, rtol=1e-5, atol=1e-6)
+    img = a.cpu().numpy().reshape(-1, 3)
+    for row in (900, 1300):
+        oimg, _ = o.render(0, 2, px_begin=row * w, px_end=(row + 1) * w)
+        assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0
+
+
+def test_full_size_properties_c2():
+    """BASELINE config C2 at full size (69 451 triangles, 1024x1024), three samples per pixel: split range, four tile
+    shards, idempotence, and three pixel rows against the oracle."""
+    s, bvh, o = get_scene("bunny")
+    be = backend_for(s, bvh)
+    w, h = s["width"], s["height"]
+    assert (w, h) == (1024, 1024)
+    a = dev_image(be)
+    be.render(0, 3, a.data_ptr()); be.synchronize()
+    st = be.stats()
+    assert st["paths"] == 3 * w * h and st["rays_primary"] == st["paths"]
+    b = dev_image(be)
+    be.render(0, 2, b.data_ptr()); be.render(2, 3, b.data_ptr()); be.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    be.render(0, 3, b.data_ptr()); be.synchronize()                      # spp_begin == 0 overwrites: idempotent
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    c = dev_image(be)
+    slabs = []
+    for r in range(4):
+        be.set_shard(r, 4)
+        d = dev_image(be)
+        be.render(0, 3, d.data_ptr())
+        slab = torch.empty(be.slab_floats(), dtype=torch.float32, device="cuda")
+        be.pack_tiles(d.data_ptr(), slab.data_ptr()); be.synchronize()
+        slabs.append(slab)
+    be.unpack_tiles(torch.cat(slabs).data_ptr(), c.data_ptr()); be.synchronize()
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    img = a.cpu().numpy().reshape(-1, 3)
+    for row in (100, 512, 800):
+        oimg, _ = o.render(0, 3, px_begin=row * w, px_end=(row + 1) * w)
+        assert mismatch(img[row * w:(row + 1) * w], oimg[row * w:(row + 1) * w]) == 0
+
+
+def test_stats_per_stage_times_and_lane_loads(monkeypatch):
+    """hpt_get_stats (SURVEY.md 8b "ms per stage"): HIP-event times of render_kernel, fold_kernel, the iterative
+    trace / shade kernels and the reconstruct kernels, the number of launches a render was cut into, and (contexts
+    created under HPT_COUNT_LANE_LOADS=1) the in-kernel count of 16-B lane-loads, which is a function of the work
+    alone: the same for any schedule, and the counting kernel renders the same image."""
+    s, bvh, o = get_scene("sponza", width=192, height=108)
+    be = backend_for(s, bvh)
+    d = dev_image(be)
+    be.render(0, 6, d.data_ptr()); be.synchronize()
+    st = be.stats()
+    assert st["launches"] == 1 and st["last_kernel_ms"] > 0 and st["fold_ms"] > 0 and st["lane_loads"] == 0
+    assert st["trace_ms"] == 0 and st["shade_ms"] == 0 and st["reconstruct_ms"] == 0
+    sample = torch.rand(192 * 108 * 3, device="cuda")
+    keep = d.clone()
+    be.reconstruct(d.data_ptr(), sample.data_ptr(), 192 * 108, 5); be.synchronize()
+    assert be.stats()["reconstruct_ms"] > 0
+    be.first_bounce(); be.bounce(); be.reconstruct_paths(d.data_ptr()); be.synchronize()
+    st = be.stats()
+    assert st["trace_ms"] > 0 and st["shade_ms"] > 0 and st["reconstruct_ms"] > 0
+    monkeypatch.setenv("HPT_COUNT_LANE_LOADS", "1")
+    loads = []
+    for budget in (None, "1"):
+        if budget:
+            monkeypatch.setenv("HPT_SAMPLE_BUDGET_MB", budget)
+        be2 = backend_for(s, bvh)
+        d2 = dev_image(be2)
+        be2.render(0, 6, d2.data_ptr()); be2.synchronize()
+        st2 = be2.stats()
+        assert torch.equal(d2.view(torch.int32), keep.view(torch.int32))
+        assert (st2["launches"] > 1) == bool(budget) and st2["last_kernel_ms"] > 0 and st2["fold_ms"] > 0
+        rays = st2["rays_primary"] + st2["rays_bounce"]
+        # a ray that enters the tree loads at least the root's node (4 lane-loads); C3-like scenes ~260 per ray
+        assert 4 * st2["rays_primary"] <= st2["lane_loads"] <= 2000 * rays
+        loads.append(st2["lane_loads"])
+    assert loads[0] == loads[1]
+
+
 def test_full_size_properties_c4(monkeypatch):
     """BASELINE config C4 at full size (10 M triangles, 19.6 M reference nodes, 3840x2160), one sample per pixel:
     (1) the two triangle-record forms and an LDS stack of one entry (everything through the HBM overflow) give the
