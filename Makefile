@@ -11,10 +11,12 @@ CXX   ?= g++
 # No FMA contraction, IEEE divide/sqrt: the numerics contract of DESIGN.md §Numerics.
 # No SLP vectorisation: hipcc packs the triangle test into v_pk ops glued by ~20 v_mov (2 % slower, more VGPRs).
 # HPT_SAMPLE_BUDGET_DEFAULT_MB: sample buffer of hpt_render (paths per launch x 12 B; HPT_SAMPLE_BUDGET_MB overrides at run time).
+# HPT_NOALLOC_SCRATCH_MB: the static device array hpt_render_noalloc works in.
 SAMPLE_BUDGET_MB ?= 2048
+NOALLOC_SCRATCH_MB ?= 128
 HIPFLAGS = -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off \
            -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -Iinclude -Wall -Wno-unused-function \
-           -DHPT_SAMPLE_BUDGET_DEFAULT_MB=$(SAMPLE_BUDGET_MB)
+           -DHPT_SAMPLE_BUDGET_DEFAULT_MB=$(SAMPLE_BUDGET_MB) -DHPT_NOALLOC_SCRATCH_MB=$(NOALLOC_SCRATCH_MB)
 HOSTFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Wall
 CFLAGS_ORACLE = -O2 -std=c11 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -Wall
 

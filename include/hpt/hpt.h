@@ -129,6 +129,25 @@ int hpt_render_sample(hpt_ctx *ctx, int iteration, float *image_rgb);
  * hpt_render_sample.  Asynchronous on the context's stream. */
 int hpt_render(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image);
 
+/* hpt_render for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  NO counterpart in the reference: its kernel_execute creates and destroys every buffer per call
+ * (opencl_manager.cpp:576-604).  Same arguments, same image bit for bit as hpt_render.  Where hpt_render keeps a
+ * sample buffer and a traversal-stack overflow buffer that it allocates (and grows) on first use, this entry point
+ * places both in a static device array of hpt_noalloc_scratch_bytes() = 128 MiB that every GPU the library runs on
+ * holds until the process ends, and cuts the render into as many launches as that takes.  It calls no hipMalloc,
+ * hipFree, hipEventCreate or any other allocating routine, and records no events (hpt_get_stats reports the ray
+ * counters of the call, times read 0).  Limits: the scene must be resident (hpt_upload_bvh and hpt_upload_triangles
+ * done: the uploads build the device data), else HPT_ERR_INVALID; the stack overflow may take half of the array --
+ * the grid is shrunk until it does, and a tree for which not even one block per CU fits is refused with
+ * HPT_ERR_INVALID (no tree that hpt_upload_bvh accepts, depth <= 64, comes near that on a 256-CU device); the rest
+ * holds the samples of one launch, at least one 8x8 tile x one iteration, so any frame size and sample count
+ * renders, in more launches than hpt_render needs (C3 full frame: 50 launches, 10 % slower).  Every context on a
+ * GPU shares that GPU's array and every call overwrites what the last one left there (nothing in it needs to
+ * start at zero): two calls that overlap on one GPU (two streams, two contexts, two threads) race; calls in
+ * stream order do not. */
+int hpt_render_noalloc(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image);
+int64_t hpt_noalloc_scratch_bytes(void);
+
 /* Test hook for the bit-exact criterion: closest hit of the camera ray of
  * `iteration` for every pixel of the full image (hit_id encoding in types.h,
  * t = 1000 on a miss). Host arrays of width*height. */

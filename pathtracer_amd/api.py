@@ -23,6 +23,7 @@ C_ABI_SYMBOLS = [
     "hpt_reconstruct", "hpt_render_sample", "hpt_render", "hpt_primary_hits", "hpt_slab_floats", "hpt_pack_tiles",
     "hpt_unpack_tiles", "hpt_tonemap", "hpt_synchronize", "hpt_get_stats",
     "hpt_first_bounce", "hpt_bounce", "hpt_reconstruct_paths", "hpt_path_counts",
+    "hpt_render_noalloc", "hpt_noalloc_scratch_bytes",
 ]
 
 
@@ -59,6 +60,9 @@ def lib():
         L.hpt_reconstruct.argtypes = [vp, vp, vp, i32, i32]
         L.hpt_render_sample.argtypes = [vp, i32, vp]
         L.hpt_render.argtypes = [vp, i32, i32, vp]
+        if not os.environ.get("HPT_LIB") or hasattr(L, "hpt_render_noalloc"):     # (HPT_LIB: A/B against older builds)
+            L.hpt_render_noalloc.argtypes = [vp, i32, i32, vp]
+            L.hpt_noalloc_scratch_bytes.argtypes = []; L.hpt_noalloc_scratch_bytes.restype = C.c_int64
         L.hpt_primary_hits.argtypes = [vp, i32, vp, vp]
         L.hpt_slab_floats.argtypes = [vp]; L.hpt_slab_floats.restype = C.c_int64
         L.hpt_pack_tiles.argtypes = [vp, vp, vp]
@@ -208,6 +212,10 @@ class Backend:
 
     def render(self, spp_begin, spp_end, d_image):
         self._chk(self.L.hpt_render(self.h, spp_begin, spp_end, C.c_void_p(d_image)))
+
+    def render_noalloc(self, spp_begin, spp_end, d_image):
+        """hpt_render for callers that cannot allocate: works in the library's static 128-MiB device array."""
+        self._chk(self.L.hpt_render_noalloc(self.h, spp_begin, spp_end, C.c_void_p(d_image)))
 
     def reconstruct(self, d_image, d_sample, n_pixels, iterations):
         self._chk(self.L.hpt_reconstruct(self.h, C.c_void_p(d_image), C.c_void_p(d_sample), n_pixels, iterations))

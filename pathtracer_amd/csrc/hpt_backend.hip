@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,13 @@ constexpr int kBlock = 256;
 #define HPT_N_COUNTERS 16
 #define HPT_COUNTER_LOADS 15        // render_kernels.h: 16-B lane-loads
 
+// Scratch of hpt_render_noalloc (include/hpt/hpt.h): the traversal-stack overflow and the sample buffer of a render
+// that may not allocate.  One array per GPU (every device that loads this code object holds its own copy at its own
+// address until the process ends); the host code never uses the NAME of the array as an address, only the pointer
+// hipGetSymbolAddress() returned for the device at hand (scratch_of()).
+constexpr size_t kScratchBytes = (size_t)HPT_NOALLOC_SCRATCH_MB << 20;
+constexpr size_t kScratchSpillMax = kScratchBytes / 2;        // the stack overflow may take at most half
+constexpr int kMaxDevices = 64;
 
 // occupancy of a persistent kernel at a dynamic-LDS size: asked of the runtime once, not on every launch
 struct KernelShape {
@@ -36,6 +44,28 @@ struct KernelShape {
     int blocks_per_cu;
 };
 
+}  // namespace
+
+static __device__ __align__(256) unsigned char hpt_noalloc_scratch[kScratchBytes];
+
+namespace {
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[kMaxDevices] = {};          // per device: the address of ITS copy of hpt_noalloc_scratch
+
+// Address of the current device's scratch array, looked up once per device (with that device current).
+hipError_t scratch_of(int device, void **out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(hpt_noalloc_scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 }  // namespace
 
 struct hpt_ctx {
@@ -88,6 +118,7 @@ struct hpt_ctx {
     hipEvent_t ev_recon[2] = {nullptr, nullptr};
     bool timed_iter = false, timed_recon = false;
     std::vector<KernelShape> shapes;
+    unsigned char *scratch = nullptr;        // this device's hpt_noalloc_scratch (hipGetSymbolAddress at hpt_create)
     int n_cu = 256;
     int grid_waves = 0;
     int shade_threshold = 24;        // scheduling knob of render_kernel (results do not depend on it): 24, up to 40 with the length of the
@@ -296,7 +327,10 @@ int kernel_shape(hpt_ctx *ctx, const void *kernel, size_t lds, int &blocks_per_c
 
 // Launch shape of a persistent traversal kernel (render_kernel, iter_trace_kernel): LDS for the capped
 // traversal stack, as many blocks as stay resident, HBM overflow of the stack sized for that grid.
-int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t &lds, long &blocks_max) {
+// noalloc: the overflow lives at the start of the device's static scratch array (and the grid shrinks until it
+// fits half of it); *scratch_used receives the bytes taken.
+int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t &lds, long &blocks_max,
+                       bool noalloc = false, size_t *scratch_used = nullptr) {
     const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
     const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
     lds = (size_t)cap * kBlock * sizeof(uint2);
@@ -308,6 +342,16 @@ int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t
     blocks_max = (long)per_cu * ctx->n_cu;
     p.stack_cap = cap;
     const size_t per_block = (size_t)(depth - cap) * kBlock * sizeof(uint2);
+    if (noalloc) {
+        if (per_block > 0 && (size_t)blocks_max * per_block > kScratchSpillMax) blocks_max = (long)(kScratchSpillMax / per_block);
+        if (blocks_max < ctx->n_cu)
+            return fail(ctx, HPT_ERR_INVALID, "hpt_render_noalloc: a tree of depth %d needs %zu B of stack overflow per block; "
+                                              "fewer than one block per CU fits the %zu MB scratch", depth, per_block, kScratchBytes >> 20);
+        const size_t used = ((size_t)blocks_max * per_block + 255) & ~(size_t)255;
+        if (scratch_used) *scratch_used = used;
+        p.spill = reinterpret_cast<uint2 *>(ctx->scratch);
+        return HPT_OK;
+    }
     const size_t spill_need = (size_t)blocks_max * per_block;
     if (spill_need > ctx->spill_bytes) {
         if (ctx->d_spill) { HIP_TRY(ctx, hipFree(ctx->d_spill)); ctx->d_spill = nullptr; ctx->spill_bytes = 0; }
@@ -333,8 +377,12 @@ int render_events(hpt_ctx *ctx, int launch) {
 // iteration when that fits; else all iterations of as many 8x8 tiles as fit (a pixel is then folded once); else,
 // for very long renders, one tile range and several iteration batches.  The split changes nothing in the image:
 // fold_kernel folds a pixel's samples in iteration order whatever launch made them.
-int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int raw) {
+// noalloc (hpt_render_noalloc): nothing is allocated -- the stack overflow and the samples live in the device's
+// static scratch array, no events are created or recorded.
+int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int raw, bool noalloc = false) {
     RenderParams p;
+    if (noalloc && ctx->pairs_dirty && ctx->root_ref_tris != HPT_REF_DONE && ctx->max_leaf_end <= ctx->n_tris)
+        return fail(ctx, HPT_ERR_INVALID, "hpt_render_noalloc: the scene is not resident yet (upload the BVH and the triangles first)");
     int rc = fill_params(ctx, p, d_image, spp_begin, spp_end, raw);
     if (rc) return rc;
     if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
@@ -353,15 +401,16 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     if (total <= 0) return HPT_OK;
 
     size_t lds; long blocks_max;
+    size_t scratch_used = 0;
     typedef void (*render_fn)(const RenderParams);
     const render_fn fn = ctx->count_loads ? (ctx->singles ? render_kernel<true, true> : render_kernel<false, true>)
                                           : (ctx->singles ? render_kernel<true, false> : render_kernel<false, false>);
-    if ((rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max))) return rc;
+    if ((rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max, noalloc, &scratch_used))) return rc;
 
     // paths (= 12-B samples) per launch: the sample buffer, and 32-bit work indices with headroom for the work
     // counter's overshoot (one chunk of <= 4096 per wave, < 2^16 waves)
     const size_t sample_bytes = 3 * sizeof(float);
-    size_t capacity = ctx->sample_budget_bytes / sample_bytes;
+    size_t capacity = (noalloc ? kScratchBytes - scratch_used : ctx->sample_budget_bytes) / sample_bytes;
     if (capacity > 0xF0000000u) capacity = 0xF0000000u;
     if (capacity < 64) capacity = 64;                     // (a budget below one tile: one tile, one iteration at a time)
     uint32_t range_slots; int batch;
@@ -370,7 +419,8 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     else { range_slots = 64; batch = (int)(capacity / 64); }
     if (range_slots > shard_slots) range_slots = shard_slots;
 
-    {
+    if (noalloc) p.samples = reinterpret_cast<float *>(ctx->scratch + scratch_used);
+    else {
         size_t samples_need = (size_t)range_slots * (size_t)batch * sample_bytes;
         while (samples_need > ctx->samples_bytes) {
             if (ctx->d_samples) { HIP_TRY(ctx, hipFree(ctx->d_samples)); ctx->d_samples = nullptr; ctx->samples_bytes = 0; }
@@ -403,15 +453,16 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
             p.spill_stride = (uint32_t)(blocks * kBlock);
             p.tail_items = (uint32_t)ctx->tail_chunks * (uint32_t)ctx->grid_waves * (uint32_t)p.fetch_chunk;
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
-            if ((rc = render_events(ctx, launch))) return rc;
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch], ctx->stream));
+            if (!noalloc) {
+                if ((rc = render_events(ctx, launch))) return rc;
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch], ctx->stream));
+            }
             hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch + 1], ctx->stream));
+            if (!noalloc) HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch + 1], ctx->stream));
             hipLaunchKernelGGL(fold_kernel, dim3((p.n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, p);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch + 2], ctx->stream));
-            ctx->timed_launches = launch + 1;
+            if (!noalloc) { HIP_TRY(ctx, hipEventRecord(ctx->ev_render[3 * launch + 2], ctx->stream)); ctx->timed_launches = launch + 1; }
         }
     }
     ctx->launches = launch;
@@ -475,6 +526,10 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
         ctx->ev_render.push_back(ev);
     }
     ctx->shapes.reserve(16);
+    // this device's copy of the no-allocation scratch array (hpt_render_noalloc), looked up with the device current
+    void *scratch = nullptr;
+    if ((e = scratch_of(device, &scratch)) != hipSuccess) return bail("hipGetSymbolAddress(hpt_noalloc_scratch)", e);
+    ctx->scratch = static_cast<unsigned char *>(scratch);
     *out = ctx;
     return HPT_OK;
 }
@@ -646,6 +701,16 @@ int hpt_render(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image) {
     if (spp_end == spp_begin) return HPT_OK;
     return launch_render(ctx, d_image, spp_begin, spp_end, 0);
 }
+
+int hpt_render_noalloc(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image || spp_begin < 0 || spp_end < spp_begin) return fail(ctx, HPT_ERR_INVALID, "bad render range [%d,%d)", spp_begin, spp_end);
+    if (spp_end == spp_begin) return HPT_OK;
+    return launch_render(ctx, d_image, spp_begin, spp_end, 0, true);
+}
+
+int64_t hpt_noalloc_scratch_bytes(void) { return (int64_t)kScratchBytes; }
 
 int hpt_kernel_execute(hpt_ctx *ctx, hpt_pixel *image, int iteration) {
     int rc = bind(ctx);
