@@ -59,7 +59,14 @@ scenes: scenes/libhpt_scenes.so
 scenes/libhpt_scenes.so: scenes/scenes.c
 	$(CC) -O2 -std=c11 -fPIC -ffp-contract=off -shared scenes/scenes.c -o $@ -lm
 
+# micro-benchmarks behind the roofline ceilings (profiles/): build/gather_exec, build/gather_rate, ...
+MICRO = $(patsubst bench/micro/%.hip,build/%,$(wildcard bench/micro/*.hip))
+micro: $(MICRO)
+build/%: bench/micro/%.hip
+	mkdir -p build
+	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 $< -o $@
+
 clean:
 	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o
 
-.PHONY: all lib cli oracle scenes clean variant
+.PHONY: all lib cli oracle scenes clean variant micro

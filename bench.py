@@ -24,24 +24,56 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ENGINE_CLOCK_HZ = 2.4e9         # MI355X peak engine clock (same guide)
-# vector-L1 ceiling for 16-B-per-lane gathers, measured with bench/micro/gather_exec.hip (node-shaped fetches
-# from an L2-resident table: 1.35; L1-resident: 1.45-1.58 lane-loads per clock per CU)
-L1_GATHER_CEILING = 1.45
+VALU_PEAK_TFLOPS = 157.3        # fp32 vector peak (same guide)
+# Ceiling of the vector L1 for 16-B-per-lane gathers, in lane-loads per clock per CU: the rate of
+# bench/micro/gather_exec.hip for node-shaped fetches (the four quarters of one 64-B line per lane, what the NODE
+# step issues) and for single 4-/8-byte gathers from an L1-resident table with all 64 lanes active (1.48 / 1.49: the
+# best case of any gather; 1.36 when the table is L2-resident, 1.08-1.34 with 32 of 64 lanes active); its output and
+# the rocprofv3 trace of that run are profiles/r02/gather_exec.txt and profiles/r02/gather_exec_kernel_stats.csv.
+L1_GATHER_CEILING = 1.49
+LANE_LOAD_BYTES = 16
 
 
-def algorithmic_bytes(costs, rays_primary, rays_bounce, n_pixels, spp):
-    """bytes(ray) = 40*N_nodes + 48*N_tris + 144, N_* = reference-order counts measured by the
-    CPU oracle (bench/frozen_costs.json); + 28*W*H per accumulated sample."""
+def kernel_source_hash():
+    """sha1 of the sources the render kernel is built from: PMC-derived figures in profiles/pmc_traffic.json carry
+    the hash they were measured at and are reported only while it still matches (they go stale with the kernel)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("pathtracer_amd/csrc/render_kernels.h", "pathtracer_amd/csrc/device_math.h", "pathtracer_amd/csrc/hpt_backend.hip", "Makefile"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def reference_costs(costs, rays_primary, rays_bounce, n_pixels, spp):
+    """bytes(ray) = 40*N_nodes + 48*N_tris + 144, flops(ray) = 12*N_nodes + 45*N_tris, N_* =
+    reference-order counts measured by the CPU oracle (bench/frozen_costs.json); + 28*W*H bytes per accumulated sample."""
     bp = 40.0 * costs["nodes_per_primary_ray"] + 48.0 * costs["tris_per_primary_ray"] + 144.0
     bb = 40.0 * costs["nodes_per_bounce_ray"] + 48.0 * costs["tris_per_bounce_ray"] + 144.0
-    return rays_primary * bp + rays_bounce * bb + 28.0 * n_pixels * spp
+    fp = 12.0 * costs["nodes_per_primary_ray"] + 45.0 * costs["tris_per_primary_ray"]
+    fb = 12.0 * costs["nodes_per_bounce_ray"] + 45.0 * costs["tris_per_bounce_ray"]
+    return (rays_primary * bp + rays_bounce * bb + 28.0 * n_pixels * spp, rays_primary * fp + rays_bounce * fb, bp, bb)
 
 
-def cpu_baseline(scn, bvh, seconds_target=15.0):
-    """Times the CPU oracle (kind "port": scalar C restatement, OpenMP over pixels) on a bounded sample:
-    the same frame at a reduced sample count, grown until ~seconds_target of CPU work."""
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def cpu_baseline(scn, bvh, seconds_target=14.0):
+    """Times the CPU oracle (kind "port": scalar C restatement of the reference kernels, OpenMP over 16x16 pixel
+    tiles) on a bounded sample of the same frame: the whole frame at a reduced sample count on every core this job
+    may use (OMP_NUM_THREADS -- the GPU box gives a 1-GPU job 16 of the host's cores -- else all of them), grown
+    until ~seconds_target of work, and one thread on a band of rows for the single-thread figure."""
     from oracle import binding as orc
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    model, n_logical = host_cpu()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or n_logical
     o = orc.OracleScene(bvh["triangles"], bvh["bbox"], bvh["info"], scn["primitives"], scn["materials"], scn["camera"],
                         scn["width"], scn["height"], scn["cfg"])
     t0 = time.perf_counter()
@@ -56,10 +88,43 @@ def cpu_baseline(scn, bvh, seconds_target=15.0):
         dt = time.perf_counter() - t0
         rays = c["rays_primary"] + c["rays_bounce"]
         spp = extra
+    # one thread: a band of rows in the middle of the frame, sized from the multi-thread rate to ~4 s
+    w, h = scn["width"], scn["height"]
+    rows = int(max(1, min(h, 4.0 * (rays / dt / threads) / (rays / spp / h))))
+    r0 = (h - rows) // 2
+    t1 = time.perf_counter()
+    _, c1 = o.render(0, 1, n_threads=1, px_begin=r0 * w, px_end=(r0 + rows) * w)
+    dt1 = time.perf_counter() - t1
+    rays1 = c1["rays_primary"] + c1["rays_bounce"]
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "%s, full %dx%d frame at %d spp (%d rays, %.1f s)" % (scn["label"].split(" ")[0], scn["width"], scn["height"], spp, rays, dt),
+            "sample": "%s, full %dx%d frame at %d spp (%d rays, %.1f s)" % (scn["label"].split(" ")[0], w, h, spp, rays, dt),
+            "one_thread_value": rays1 / dt1 / 1e6,
+            "one_thread_sample": "rows %d..%d of the frame at 1 spp (%d rays, %.1f s)" % (r0, r0 + rows - 1, rays1, dt1),
+            "host_cpu_model": model, "host_logical_cpus": n_logical,
+            "threads_note": "OMP_NUM_THREADS=%s" % os.environ.get("OMP_NUM_THREADS", "unset (all logical CPUs)"),
             "nodes_per_ray": (c["nodes_primary"] + c["nodes_bounce"]) / rays,
             "tris_per_ray": (c["tris_primary"] + c["tris_bounce"]) / rays}
+
+
+def count_lane_loads(api, scn, bvh, w, h, spp, device, rank, world, shard):
+    """One more frame, outside the timed region, through the counting build of render_kernel (a context created
+    under HPT_COUNT_LANE_LOADS=1): the 16-B lane-loads of exactly this frame, counted in the kernel."""
+    import torch
+    os.environ["HPT_COUNT_LANE_LOADS"] = "1"
+    try:
+        be = api.Backend(w, h, device=device)
+    finally:
+        del os.environ["HPT_COUNT_LANE_LOADS"]
+    be.load(scn, bvh)
+    if shard == "tiles":
+        be.set_shard(rank, world)
+    else:
+        be.set_sample_shard(rank, world)
+    img = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    be.render(0, spp, img.data_ptr())
+    st = be.stats()
+    be.close()
+    return st["lane_loads"], st["rays_primary"] + st["rays_bounce"], st["last_kernel_ms"]
 
 
 def main():
@@ -70,6 +135,8 @@ def main():
     ap.add_argument("--scene", default="sponza", help="sponza (C3, headline) | bunny (C2) | cornell (C1) | glossy (C5) | tenm (C4)")
     ap.add_argument("--spp", type=int, default=0, help="override the config's spp (debugging only: makes the number non-headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-count", action="store_true", help="skip the extra, untimed frame through the counting kernel (PMC passes: "
+                                                            "only the timed kernel may run); the l1_gather fields are then null")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "samples"],
                     help="N>1: tiles = 8x8 tiles round-robin + one all-gather (bit-identical image, the default); "
                          "samples = iterations s %% N == rank + one all-reduce (SURVEY.md 8e secondary mode)")
@@ -113,19 +180,14 @@ def main():
         be.set_sample_shard(rank, world)
     be.set_stream(torch.cuda.current_stream().cuda_stream)
     image = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    exchange = pdist.Exchange(be, image, world) if world > 1 else None
 
     def step():
         be.render(0, spp, image.data_ptr())
         if world > 1 and args.shard == "tiles":
-            pdist.gather_image(be, image, world)
+            exchange.gather()                             # pack -> all-gather -> unpack, in stream order under RCCL
         elif world > 1:
-            be.synchronize()
-            if dist_backend == "nccl":
-                pdist.reduce_samples(image, pdist.sample_shard_count(0, spp, rank, world), spp)
-            else:                                         # gloo rehearsal: stage through the host
-                host = image.cpu()
-                pdist.reduce_samples(host, pdist.sample_shard_count(0, spp, rank, world), spp)
-                image.copy_(host)
+            exchange.reduce(pdist.sample_shard_count(0, spp, rank, world), spp)
 
     def fence():
         be.synchronize()
@@ -138,7 +200,7 @@ def main():
         step()
     fence()
     kernel_ms = []
-    rays_p = rays_b = 0
+    rays_p = rays_b = launches = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -146,7 +208,7 @@ def main():
         # HIP-event time of the render kernel recorded on that stream
         st = be.stats()
         kernel_ms.append(st["last_kernel_ms"])
-        rays_p, rays_b = st["rays_primary"], st["rays_bounce"]
+        rays_p, rays_b, launches = st["rays_primary"], st["rays_bounce"], st["launches"]
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -161,43 +223,68 @@ def main():
         kern_ms = float(tot[3])
     rays_frame = rays_p + rays_b
 
+    # lane-loads of this rank's share of the frame (counting kernel, untimed); N>1: rank 0's share stands for all
+    lane_loads = counted_rays = None
+    if rank == 0 and not args.no_count:
+        lane_loads, counted_rays, _ = count_lane_loads(api, scn, bvh, w, h, spp, local_rank, rank, world, args.shard)
+
     if rank == 0:
         costs_all = json.load(open(os.path.join(ROOT, "bench", "frozen_costs.json")))
         costs = costs_all.get(args.scene)
-        roofline = None
+        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        scene_mb = (len(bvh["bbox"]) * 40 + len(bvh["triangles"]) * 48) / 1e6
+        cache_resident = scene_mb <= 256
+        t_kernel = kern_ms * 1e-3
+        # the vector-L1 gather roofline: what the kernel asks of the L1 (counted in the kernel) over the kernel's time
+        l1_gbps = lane_loads * LANE_LOAD_BYTES / t_kernel / 1e9 if lane_loads else None
+        l1_peak_gbps = L1_GATHER_CEILING * LANE_LOAD_BYTES * n_cu * ENGINE_CLOCK_HZ / 1e9
+        # PMC-derived figures (separate rocprofv3 --pmc passes, bench/pmc.sh): only while measured at this kernel
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        khash = kernel_source_hash()
+        if os.path.exists(pmc_path) and world == 1 and not args.spp:
+            pmc = json.load(open(pmc_path)).get(args.scene, {})
+            if pmc.get("kernel_source_hash") != khash:
+                pmc = {}
+        traffic = pmc.get("hbm_bytes_per_launch")
+        hbm_traffic_gbps = traffic / t_kernel / 1e9 if traffic else None
+        roofline = {"kernel": "render_kernel", "kernel_ms": kern_ms, "unit": "GB/s", "traffic": traffic,
+                    "kernel_source_hash": khash, "pmc_measured_at_this_hash": bool(pmc),
+                    # vector-L1 gather
+                    "lane_loads_per_launch": lane_loads, "lane_loads_per_ray": lane_loads / counted_rays if lane_loads else None,
+                    "lane_loads_per_clk_per_cu": lane_loads / t_kernel / n_cu / ENGINE_CLOCK_HZ if lane_loads else None,
+                    "l1_gather_ceiling_lane_loads_per_clk_per_cu": L1_GATHER_CEILING,
+                    "l1_gather_gbps": l1_gbps, "l1_gather_peak_gbps": l1_peak_gbps,
+                    "l1_gather_frac": l1_gbps / l1_peak_gbps if l1_gbps else None,
+                    "dispatches_per_launch": launches,
+                    # HBM side, measured (fabric-side bytes of the PMC passes over this run's kernel time)
+                    "hbm_traffic_gbps": hbm_traffic_gbps,
+                    "hbm_traffic_frac": hbm_traffic_gbps / HBM_PEAK_GBPS if hbm_traffic_gbps else None,
+                    "l2_hit_rate": pmc.get("l2_hit_rate"), "l1_miss_to_l2_frac": pmc.get("l1_miss_to_l2_frac"),
+                    "valu_busy_frac_of_cu_time": pmc.get("valu_busy_frac_of_cu_time"), "lane_utilisation": pmc.get("lane_utilisation"),
+                    "tcp_lane_accesses_per_launch": pmc.get("tcp_lane_accesses_per_launch")}
         if costs:
             # per launch = per rank per frame; with N ranks each launch handles 1/N of the frame's rays
-            alg = algorithmic_bytes(costs, rays_p / world, rays_b / world, w * h / world, spp)
-            achieved = alg / (kern_ms * 1e-3) / 1e9
-            traffic = None
-            gather = None
-            scene_mb = (len(bvh["bbox"]) * 40 + len(bvh["triangles"]) * 48) / 1e6
-            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc_path) and world == 1 and not args.spp:
-                pmc = json.load(open(pmc_path)).get(args.scene, {})
-                traffic = pmc.get("hbm_bytes_per_launch")
-                if pmc.get("tcp_lane_accesses_per_launch"):
-                    # what actually bounds the kernel: lane-loads served by the vector L1 per clock per CU
-                    n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
-                    rate = pmc["tcp_lane_accesses_per_launch"] / (kern_ms * 1e-3) / n_cu / ENGINE_CLOCK_HZ
-                    gather = {"lane_loads_per_clk_per_cu": rate, "ceiling": L1_GATHER_CEILING, "frac": rate / L1_GATHER_CEILING,
-                              "lane_loads_per_ray": pmc["tcp_lane_accesses_per_launch"] / rays_frame,
-                              "source": "TCP_TOTAL_CACHE_ACCESSES of profiles/pmc_traffic.json over this run's kernel time"}
-            roofline = {"bound": "hbm", "kernel": "render_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
-                        "bytes_per_primary_ray": 40.0 * costs["nodes_per_primary_ray"] + 48.0 * costs["tris_per_primary_ray"] + 144.0,
-                        "bytes_per_bounce_ray": 40.0 * costs["nodes_per_bounce_ray"] + 48.0 * costs["tris_per_bounce_ray"] + 144.0,
-                        "l1_gather": gather,
-                        # SURVEY.md 8d asks for these beside the HBM fraction (same PMC run as `traffic`)
-                        "pmc": ({k: pmc[k] for k in ("l2_hit_rate", "l1_miss_to_l2_frac", "valu_busy_frac_of_cu_time", "lane_utilisation") if k in pmc}
-                                if traffic is not None else None),
-                        "note": ("BVH+triangles (%.0f MB) are cache-resident, so algorithmic bytes/s can exceed the HBM peak; "
-                                 "the measured limiter is the vector-L1 gather rate (l1_gather); see DESIGN.md §Roofline"
-                                 if scene_mb <= 256 else
-                                 "BVH+triangles (%.0f MB) exceed the 256 MB Infinity Cache: the top of the tree still hits in "
-                                 "cache, the rest streams from HBM (PMC: profiles/r01_final/other_configs); see DESIGN.md §Roofline")
-                                % scene_mb}
+            alg_bytes, alg_flops, bp, bb = reference_costs(costs, rays_p / world, rays_b / world, w * h / world, spp)
+            roofline.update({
+                # SURVEY.md 8d's reference-order algorithmic bytes: NOT a bound of this kernel on a cache-resident scene
+                # (path state stays in registers, nodes come from L1/L2), kept for comparison with the reference's traffic
+                "hbm_algorithmic_bytes_per_launch": alg_bytes, "hbm_algorithmic_gbps": alg_bytes / t_kernel / 1e9,
+                "bytes_per_primary_ray": bp, "bytes_per_bounce_ray": bb,
+                # SURVEY.md 8d's flop count of the reference-order work against the fp32 vector peak
+                "valu_algorithmic_tflops": alg_flops / t_kernel / 1e12,
+                "valu_algorithmic_frac": alg_flops / t_kernel / 1e12 / VALU_PEAK_TFLOPS})
+        if cache_resident:
+            roofline.update({"bound": "l1_gather", "achieved": l1_gbps, "peak": l1_peak_gbps, "frac": l1_gbps / l1_peak_gbps if l1_gbps else None,
+                             "note": "BVH+triangles (%.0f MB) are cache-resident: HBM does not bind (hbm_traffic_frac), the vector L1's "
+                                     "gather rate does; achieved = lane-loads counted in the kernel x 16 B / kernel time, peak = "
+                                     "%.2f lane-loads/clk/CU (profiles/r02/gather_exec.txt) x 16 B x %d CUs x 2.4 GHz" % (scene_mb, L1_GATHER_CEILING, n_cu)})
+        else:
+            roofline.update({"bound": "hbm", "achieved": hbm_traffic_gbps, "peak": HBM_PEAK_GBPS,
+                             "frac": hbm_traffic_gbps / HBM_PEAK_GBPS if hbm_traffic_gbps else None,
+                             "note": "BVH+triangles (%.0f MB) exceed the 256 MB Infinity Cache and stream from HBM; achieved = fabric-side "
+                                     "bytes of the PMC passes (FETCH_SIZE x2 per the guide + WRITE_SIZE, profiles/pmc_traffic.json) over this "
+                                     "run's kernel time, null when those passes were not measured at this kernel" % scene_mb})
         out = {
             "metric": "Mrays/s (primary+bounce); ms_per_step = ms/frame %dx%d %dspp" % (w, h, spp),
             "value": rays_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",

@@ -3,7 +3,7 @@
 # FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2).  Usage (on the GPU box, from the repo root):
 #   bash bench/pmc.sh <tag> [bench.py args...]        -> gpurun_out/pmc_<tag>/<pass>_counter_collection.csv
 tag=$1; shift
-args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline}
+args=${@:---steps 1 --warmup 0 --no-cpu-baseline --no-count}
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 run() {

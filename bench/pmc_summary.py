@@ -8,6 +8,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (bench.py at the repo root)
+
 d = sys.argv[1]
 agg = collections.defaultdict(float)
 launches = 0
@@ -19,7 +22,12 @@ for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
             seen.add(r["Dispatch_Id"])
     launches = max(launches, len(seen))
 a = dict(agg)
+# "launch" in the roofline = one hpt_render call = one frame, which the backend may cut into several dispatches of
+# render_kernel (sample buffer); the PMC passes run bench.py for PMC_FRAMES frames (default 1)
+a["dispatches"] = launches
+launches = int(os.environ.get("PMC_FRAMES", "1"))
 a["launches"] = launches
+a["kernel_source_hash"] = kernel_source_hash()      # bench.py reports these figures only while the kernel is this one
 g = a.get
 if g("SQ_ACTIVE_INST_VALU"):
     a["lane_utilisation"] = a["SQ_THREAD_CYCLES_VALU"] / (a["SQ_ACTIVE_INST_VALU"] * 64)

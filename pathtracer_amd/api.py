@@ -142,6 +142,7 @@ class Backend:
             raise HptError("hpt_create: %s" % self.L.hpt_last_error(None).decode(), rc)
         self.h = h
         self.width, self.height = width, height
+        self.stream_handle = 0
 
     def close(self):
         if getattr(self, "h", None):
@@ -160,6 +161,7 @@ class Backend:
 
     def set_stream(self, stream_handle):
         self._chk(self.L.hpt_set_stream(self.h, C.c_void_p(stream_handle)))
+        self.stream_handle = stream_handle              # dist.Exchange: same stream as the collective -> no host syncs
 
     def set_shard(self, rank, world):
         self._chk(self.L.hpt_set_shard(self.h, rank, world))

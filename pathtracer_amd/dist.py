@@ -54,29 +54,84 @@ def unpack_tiles_np(slabs, width, height, world, image=None):
     return image
 
 
+class Exchange:
+    """The exchange step of one backend: its slab buffers, allocated once, and the collectives in STREAM ORDER.
+
+    With the RCCL backend and the backend launching on torch's current stream (`be.set_stream(
+    torch.cuda.current_stream().cuda_stream)`), pack -> all_gather_into_tensor -> unpack needs no host
+    synchronisation: the kernels are on the current stream, and torch orders its collective after the work already
+    queued there and the stream's later work after the collective.  Any other arrangement (gloo rehearsal, a
+    backend on a stream of its own) falls back to host synchronisation around the collective."""
+
+    def __init__(self, backend, image, world, group=None):
+        import torch
+        import torch.distributed as dist
+        self.backend, self.image, self.world, self.group = backend, image, world, group
+        self.gloo = dist.get_backend(group) == "gloo"
+        self.n = -1
+        self._buffers()
+
+    def _buffers(self):
+        """(Re)allocates the slab buffers when the backend's shard, and with it the slab size, has changed."""
+        import torch
+        n = self.backend.slab_floats()
+        if n == self.n:
+            return
+        self.n = n
+        self.slab = torch.empty(n, dtype=torch.float32, device=self.image.device)
+        self.slabs = torch.empty(n * self.world, dtype=torch.float32, device=self.image.device)
+        self.host_parts = [torch.empty(n, dtype=torch.float32) for _ in range(self.world)] if self.gloo else None
+
+    def _stream_ordered(self):
+        import torch
+        return (not self.gloo) and getattr(self.backend, "stream_handle", None) == torch.cuda.current_stream().cuda_stream
+
+    def gather(self):
+        """Tile shards: every rank's tiles of `image` -> the full image on every rank (ONE all-gather)."""
+        import torch
+        import torch.distributed as dist
+        be = self.backend
+        self._buffers()
+        ordered = self._stream_ordered()
+        be.pack_tiles(self.image.data_ptr(), self.slab.data_ptr())
+        if self.gloo:                                   # rehearsal on a box with fewer GPUs than ranks: stage through the host
+            be.synchronize()
+            dist.all_gather(self.host_parts, self.slab.cpu(), group=self.group)
+            self.slabs.copy_(torch.cat(self.host_parts))
+            torch.cuda.current_stream().synchronize()
+        else:
+            if not ordered:
+                be.synchronize()
+            dist.all_gather_into_tensor(self.slabs, self.slab, group=self.group)
+            if not ordered:
+                torch.cuda.current_stream().synchronize()
+        be.unpack_tiles(self.slabs.data_ptr(), self.image.data_ptr())
+        if not ordered:
+            be.synchronize()
+        return self.image
+
+    def reduce(self, n_local, n_total):
+        """Sample shards: this rank's running mean over its n_local samples -> the frame's mean (ONE all-reduce)."""
+        if self.gloo:
+            self.backend.synchronize()
+            host = self.image.cpu()
+            reduce_samples(host, n_local, n_total, group=self.group)
+            self.image.copy_(host)
+            return self.image
+        if not self._stream_ordered():
+            self.backend.synchronize()
+        return reduce_samples(self.image, n_local, n_total, group=self.group)
+
+
 def gather_image(backend, image, world, group=None):
-    """All-gather the shards of a device-resident image (torch tensor [h*w*3] float32 on the
-    backend's device) into every rank's `image`.  No-op when world == 1."""
+    """All-gather the shards of a device-resident image (torch tensor [h*w*3] float32 on the backend's device)
+    into every rank's `image`.  No-op when world == 1.  The slab buffers are allocated once per backend."""
     if world == 1:
         return image
-    import torch
-    import torch.distributed as dist
-    n = backend.slab_floats()
-    slab = torch.empty(n, dtype=torch.float32, device=image.device)
-    slabs = torch.empty(n * world, dtype=torch.float32, device=image.device)
-    backend.pack_tiles(image.data_ptr(), slab.data_ptr())
-    # the pack kernel runs on the backend's stream; the collective on torch's current stream
-    backend.synchronize()
-    if dist.get_backend(group) == "gloo":           # rehearsal on a box with fewer GPUs than ranks: stage through the host
-        parts = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
-        dist.all_gather(parts, slab.cpu(), group=group)
-        slabs.copy_(torch.cat(parts))
-    else:
-        dist.all_gather_into_tensor(slabs, slab, group=group)
-    torch.cuda.current_stream().synchronize()
-    backend.unpack_tiles(slabs.data_ptr(), image.data_ptr())
-    backend.synchronize()
-    return image
+    ex = getattr(backend, "_exchange", None)
+    if ex is None or ex.image.data_ptr() != image.data_ptr() or ex.world != world or ex.group is not group:
+        ex = backend._exchange = Exchange(backend, image, world, group)
+    return ex.gather()
 
 
 def gather_image_cpu(slab, world, group=None):
@@ -100,7 +155,7 @@ def reduce_samples(image, n_local, n_total, group=None):
     """Combines the per-rank running means of a sample-sharded render into the frame's mean, in place on every
     rank: image <- sum_r (n_r / N) * image_r, ONE all-reduce (RCCL when the group's backend is "nccl", gloo on
     CPU tensors in the tests).  `image` is this rank's mean over its n_local samples (a torch tensor, device or
-    CPU); the backend's stream must have been synchronised.  fp32 sum in rank order of the collective: within
+    CPU); the render must be complete in the collective's stream order (Exchange.reduce sees to that).  fp32 sum in rank order of the collective: within
     1e-5 relative of the unsharded running mean, not bit-identical to it."""
     import torch.distributed as dist
     image.mul_(float(n_local) / float(n_total))

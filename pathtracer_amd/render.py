@@ -95,17 +95,12 @@ def main(argv=None):
     image = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
     t0 = time.perf_counter()
     be.render(0, spp, image.data_ptr())
-    if world > 1 and a.shard == "tiles":
-        pdist.gather_image(be, image, world)
-    elif world > 1:
-        be.synchronize()
-        n_local = pdist.sample_shard_count(0, spp, rank, world)
-        if backend == "nccl":
-            pdist.reduce_samples(image, n_local, spp)
+    if world > 1:
+        exchange = pdist.Exchange(be, image, world)
+        if a.shard == "tiles":
+            exchange.gather()
         else:
-            host = image.cpu()
-            pdist.reduce_samples(host, n_local, spp)
-            image.copy_(host)
+            exchange.reduce(pdist.sample_shard_count(0, spp, rank, world), spp)
     be.synchronize()
     torch.cuda.synchronize()
     t_render = time.perf_counter() - t0

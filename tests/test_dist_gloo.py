@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -85,3 +86,59 @@ def test_two_rank_sample_shard_reduce():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _device_worker(rank, world, port, w, h, spp, mode, q):
+    """One rank of a 2-process render that shares ONE GPU: the device kernels hpt_pack_tiles / hpt_unpack_tiles
+    (or the sample-shard fold) on both sides of a gloo collective, through dist.Exchange."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from pathtracer_amd import api, dist as pd, scenes
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    s = scenes.scene("cornell")
+    bvh = api.build_bvh(s["verts"])
+    be = api.Backend(w, h, device=0)
+    be.load(dict(s, width=w, height=h), bvh)
+    be.set_stream(torch.cuda.current_stream().cuda_stream)
+    image = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    ex = pd.Exchange(be, image, world)
+    if mode == "tiles":
+        be.set_shard(rank, world)
+        be.render(0, spp, image.data_ptr())
+        ex.gather(); ex.gather()                          # the buffers are reused: a second exchange changes nothing
+    else:
+        be.set_sample_shard(rank, world)
+        be.render(0, spp, image.data_ptr())
+        ex.reduce(pd.sample_shard_count(0, spp, rank, world), spp)
+    be.synchronize()
+    q.put((rank, image.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tiles", "samples"])
+def test_two_ranks_device_exchange_on_one_gpu(mode):
+    """world_size 2 over gloo, both ranks on the one GPU of the box: each renders its shard through the C-ABI,
+    packs with the DEVICE kernel, exchanges, unpacks with the device kernel.  Tile shards: bit-identical to the
+    oracle's unsharded image on both ranks; sample shards: within 1e-5 (fp32 summation order)."""
+    from conftest import bits, get_scene
+    w, h, spp = 100, 52, 5
+    _, _, o = get_scene("cornell", width=w, height=h)
+    want = o.render(0, spp)[0].reshape(-1)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_device_worker, args=(r, 2, port, w, h, spp, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(2):
+        if mode == "tiles":
+            assert np.array_equal(bits(res[r]), bits(want)), r
+        else:
+            assert np.allclose(res[r], want, rtol=1e-5, atol=1e-6), r
