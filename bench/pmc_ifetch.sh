@@ -1,7 +1,7 @@
 #!/bin/bash
 # Instruction-fetch side of render_kernel (one rocprofv3 pass).  Usage: bash bench/pmc_ifetch.sh <tag> [bench.py args...]
 tag=$1; shift
-args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline}
+args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-count}
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 timeout -s KILL 180 rocprofv3 --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_BRANCH SQ_INSTS_CBRANCH SQ_INSTS_CBRANCH_TAKEN SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM --output-format csv -d $out -o if1 -- python bench.py $args > $out/if1.log 2>&1 || { echo "pass if1 failed"; tail -5 $out/if1.log; exit 1; }

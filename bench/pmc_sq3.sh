@@ -1,7 +1,7 @@
 #!/bin/bash
 # Issue-side detail of render_kernel (one rocprofv3 pass).  Usage: bash bench/pmc_sq3.sh <tag> [bench.py args...]
 tag=$1; shift
-args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline}
+args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-count}
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 timeout -s KILL 180 rocprofv3 --pmc SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC --output-format csv -d $out -o sq3 -- python bench.py $args > $out/sq3.log 2>&1 || { echo "pass sq3 failed"; tail -5 $out/sq3.log; exit 1; }
@@ -12,7 +12,7 @@ for name in ("sq3", "sq4"):
     tot = collections.defaultdict(float)
     with open(f"{sys.argv[1]}/{name}_counter_collection.csv") as f:
         for r in csv.DictReader(f):
-            if "render_kernel" in r["Kernel_Name"]:
+            if "render_kernel" in r["Kernel_Name"] or "render2_kernel" in r["Kernel_Name"]:
                 tot[r["Counter_Name"]] += float(r["Counter_Value"])
     for k, v in sorted(tot.items()): print(f"{k:32s} {v:.4g}")
 P

@@ -2,7 +2,7 @@
 # Address-translation and TA/TCP stall counters of render_kernel (three rocprofv3 passes).
 # Usage: bash bench/pmc_stall.sh <tag> [bench.py args...]
 tag=$1; shift
-args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline}
+args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-count}
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 run() {
@@ -20,7 +20,7 @@ for name in ("st1", "st2", "st3"):
     tot = collections.defaultdict(float)
     with open(path) as f:
         for r in csv.DictReader(f):
-            if "render_kernel" in r["Kernel_Name"]:
+            if "render_kernel" in r["Kernel_Name"] or "render2_kernel" in r["Kernel_Name"]:
                 tot[r["Counter_Name"]] += float(r["Counter_Value"])
     for k, v in sorted(tot.items()): print(f"{k:44s} {v:.4g}")
 P

@@ -17,7 +17,7 @@ launches = 0
 for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
     seen = set()
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"]:
+        if "render_kernel" in r["Kernel_Name"] or "render2_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             seen.add(r["Dispatch_Id"])
     launches = max(launches, len(seen))
