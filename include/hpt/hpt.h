@@ -112,7 +112,13 @@ int hpt_reconstruct(hpt_ctx *ctx, float *d_image, const float *d_sample, int n_p
  * the last hpt_bounce, d_image = (1/n)*contribution + ((n-1)/n)*d_image with n = the pixel's path counter
  * (n == 1: copy).  d_image: device pointer, width*height*3 floats.
  *
- * hpt_path_counts copies the per-pixel path counters (the reference's iteration_memory) to the host. */
+ * hpt_path_counts copies the per-pixel path counters (the reference's iteration_memory) to the host.
+ *
+ * Constants: these calls use the context's hpt_config like every other render call, whose DEFAULTS are the
+ * mega-kernel's (diffuse factor 2*dot(n,dir), pathtracer_kernel.cl:822; depth limit 15).  The kernel they replace
+ * weighs a diffuse bounce by dot(n,dir) alone and has no depth limit (ray_kernel.cl:785-786): a caller that wants
+ * the live loop's own brightness sets hpt_config.diffuse_scale = 1.0 (and a large max_depth) first.  Deliberate:
+ * one set of constants per context, so that the two pipelines converge to the same image. */
 int hpt_first_bounce(hpt_ctx *ctx);
 int hpt_bounce(hpt_ctx *ctx);
 int hpt_reconstruct_paths(hpt_ctx *ctx, float *d_image);

@@ -1,13 +1,18 @@
 // host/obj_reader.cpp — OBJ reader (see obj_reader.hpp): memory-mapped file, parsed in parallel.
 // The reference tokenises with fscanf("%s") and prints every vertex
 // (reference pathtracer/obj_reader.cpp:20-75); this one maps the file, prints nothing, and yields the same
-// vertex list on files the reference can read.  Numbers go through strtof/strtol, as fscanf's conversions do.
+// vertex list on files of `v x y z` and three-index `f a b c` lines, faces before or after the vertices they
+// name (the reference resolves indices after the whole file is read, obj_reader.cpp:77-81).  Two deliberate
+// differences: an `f` line with more than three indices is fan-triangulated here, while the
+// reference takes its first three indices and drops the rest of the line (obj_reader.cpp:45: one triangle per quad);
+// `a/b/c` tokens and negative indices, which the reference rejects or misreads, are accepted.  Numbers go through
+// strtof/strtol, as fscanf's conversions do.
 //
 // Three parallel passes over line-aligned chunks (threads = build_threads()):
 //   1. count `v` lines and output vertices (3 per fan triangle) per chunk  -> prefix sums
 //   2. parse the `v` lines into the vertex array at the chunk's offset
-//   3. parse the `f` lines; a face may only name vertices that precede it in the file (the sequential
-//      reader's rule, and what negative indices are relative to), which the chunk's running vertex count gives.
+//   3. parse the `f` lines; a positive index names a vertex of the whole file, a negative one counts back from
+//      the vertices defined before the face's line (the OBJ rule), which the chunk's running vertex count gives.
 #include "obj_reader.hpp"
 
 #include <fcntl.h>
@@ -154,6 +159,7 @@ bool load_obj(const char *path, std::vector<Vec3f> &out_vertices) {
         std::vector<long> face;
         for (long t = tb; t < te; t++) {
             long seen = v0[t];                              // vertices defined before the current line
+            const long total = v0[T];
             size_t at = base + (size_t)o0[t];
             for_lines(data + cut[t], data + cut[t + 1], [&](const Line &l) {
                 const char *body;
@@ -170,8 +176,8 @@ bool load_obj(const char *path, std::vector<Vec3f> &out_vertices) {
                     const char *e2 = end;
                     while (e2 < l.e && !blank(*e2) && !eol(*e2)) e2++;          // skip /vt/vn
                     q = e2;
-                    if (idx < 0) idx = seen + 1 + idx;
-                    if (idx < 1 || idx > seen) { ok = false; break; }
+                    if (idx < 0) { idx = seen + 1 + idx; if (idx < 1) { ok = false; break; } }
+                    if (idx < 1 || idx > total) { ok = false; break; }
                     face.push_back(idx - 1);
                 }
                 if (!ok) return;

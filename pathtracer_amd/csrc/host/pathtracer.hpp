@@ -17,6 +17,8 @@ class Pathtracer {
 public:
     Pathtracer(int w, int h, int device = 0);
     ~Pathtracer();
+    Pathtracer(const Pathtracer &) = delete;             // owns the backend context and the device image
+    Pathtracer &operator=(const Pathtracer &) = delete;
     bool ok() const { return ctx != nullptr; }
     const char *error() const;
 
@@ -35,7 +37,9 @@ public:
     Pixel *render(int n);
 
     // Progressive interface of the live GLUT loop (main.cpp:112, 130-131), with the
-    // semantics the reference intends: the first call caches bounce 0
+    // semantics the reference intends.  It runs with the same hpt_config as render(): by default
+    // the mega-kernel's constants (diffuse factor 2*cos, depth limit 15), not ray_kernel.cl's own (factor 1, no
+    // limit, ray_kernel.cl:785-786); set_config({.., .diffuse_scale = 1.0f, ..}) selects those.  The first call caches bounce 0
     // of every pixel, each iterative_render() advances every pixel's path by one bounce
     // (a path that ends restarts from the cache), reconstruct() folds the paths that
     // ended into the per-pixel running mean and refreshes get_image().

@@ -97,6 +97,7 @@ struct hpt_ctx {
     bool singles = false;            // record form of the current tree: one triangle per 48-B record (ensure_pairs)
     int leaf_records = 0;            // HPT_LEAF_RECORDS: 0 = per tree, 1 = singles, 2 = pairs
     hpt_primitive *d_prims = nullptr;
+    PrimCompact *d_prim_compact = nullptr;   // centre, radius, type, plane normal of each primitive (render_kernels.h)
     int n_prims = 0;
     hpt_material *d_mats = nullptr;
     int n_mats = 0;
@@ -270,7 +271,7 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     memset(&p, 0, sizeof p);
     p.pairs = ctx->d_pairs;
     p.singles = ctx->singles ? 1 : 0;
-    p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.mats = ctx->d_mats;
+    p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.prim_compact = ctx->d_prim_compact; p.mats = ctx->d_mats;
     p.image = d_image; p.hit_id = ctx->d_hit_id; p.hit_t = ctx->d_hit_t;
     p.work_counter = ctx->d_work; p.counters = ctx->d_counters;
     p.cam = ctx->cam;
@@ -540,7 +541,7 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);
-    (void)hipFree(ctx->d_iter); (void)hipFree(ctx->d_pairs);
+    (void)hipFree(ctx->d_iter); (void)hipFree(ctx->d_pairs); (void)hipFree(ctx->d_prim_compact);
     for (hipEvent_t ev : ctx->ev_render) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->ev_iter) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->ev_recon) if (ev) (void)hipEventDestroy(ev);
@@ -669,6 +670,12 @@ int hpt_set_scene(hpt_ctx *ctx, const hpt_primitive *primitives, int n_primitive
     if (n_primitives < 0 || n_materials < 0 || (n_primitives > 0 && !primitives) || (n_materials > 0 && !materials))
         return fail(ctx, HPT_ERR_INVALID, "bad scene arrays");
     if ((rc = replace_buffer(ctx, ctx->d_prims, primitives, (size_t)n_primitives * sizeof(hpt_primitive)))) return rc;
+    std::vector<PrimCompact> compact((size_t)n_primitives);
+    for (int i = 0; i < n_primitives; i++) {
+        const hpt_primitive &q = primitives[i];
+        compact[i] = PrimCompact{q.center.x, q.center.y, q.center.z, q.radius, q.type.x, q.plane_normal.x, q.plane_normal.y, q.plane_normal.z};
+    }
+    if ((rc = replace_buffer(ctx, ctx->d_prim_compact, compact.data(), compact.size() * sizeof(PrimCompact)))) return rc;
     if ((rc = replace_buffer(ctx, ctx->d_mats, materials, (size_t)n_materials * sizeof(hpt_material)))) return rc;
     ctx->n_prims = n_primitives; ctx->n_mats = n_materials;
     return HPT_OK;

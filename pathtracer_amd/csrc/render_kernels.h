@@ -38,6 +38,7 @@ struct RenderParams {
     const float4 *pairs;             // triangles as the traversal reads them: 80-B records of two, or 48-B records of one
                                      // (singles != 0); leaf references point here
     const hpt_primitive *prims;
+    const struct PrimCompact *prim_compact;   // the fields the closest-hit query reads of each primitive, 32 B each (long lists: two-phase loop)
     const hpt_material *mats;
     float *image;                    // width*height*3
     int32_t *hit_id;                 // primary_hits only
@@ -77,6 +78,11 @@ struct RenderParams {
 };
 
 struct Ray { f3 o, d; };
+
+// What intersect() reads of a primitive (ray_kernel.cl:524-602): centre, radius, type, plane normal.  Built by
+// hpt_set_scene beside the wire-format array; 32 B = one s_load_dwordx8 (wave-uniform index) or two 16-B lane-loads.
+struct __attribute__((aligned(32))) PrimCompact { float cx, cy, cz, radius, type, nx, ny, nz; };
+#define HPT_TWO_PHASE_MIN_PRIMS 12   // shorter lists walk the wire-format array directly (one pass, no candidate masks)
 
 // ---- camera ray: initial_ray_kernel.cl:859-883 (== pathtracer_kernel.cl:912-937) ----
 __device__ __forceinline__ Ray camera_ray(const RenderParams &p, int gid, int iteration, uint32_t key, uint32_t &ctr) {
@@ -297,6 +303,82 @@ __device__ __forceinline__ bool intersect_prim(const hpt_primitive *prim, f3 o, 
         }
     }
     return false;
+}
+
+// The same test on values held by the lane (the second phase below): the arithmetic of intersect_prim, operand for operand.
+__device__ __forceinline__ bool intersect_prim_values(float type, f3 center, float radius, f3 pn, f3 o, f3 d, float &t) {
+    if (type == 0.0f) {
+        f3 oc = o - center;
+        float a = dot3(d, d);
+        float b = 2.0f * dot3(d, oc);
+        float c = dot3(oc, oc) - (radius * radius);
+        float disc = (b * b) - ((4.0f * a) * c);
+        float tt;
+        if (disc < 0.0f) return false;
+        else if (disc < HPT_EPSILON) tt = -b / (2.0f * a);
+        else {
+            disc = sqrtf(disc);
+            float t0 = (-b - disc) / (2.0f * a);
+            if (t0 > HPT_EPSILON) tt = t0;
+            else tt = (-b + disc) / (2.0f * a);
+        }
+        if (tt < t && tt > 0.0f) { t = tt; return true; }
+    } else if (type == 1.0f) {
+        float denom = dot3(pn, d);
+        if (fabsf(denom) > HPT_EPSILON) {
+            f3 between = center - o;
+            float tt = dot3(between, pn) / denom;
+            if (tt < t && tt >= 0.0f) { t = tt; return true; }
+        }
+    }
+    return false;
+}
+
+// The primitives loop of pathtrace() (ray_kernel.cl:726-739) for long lists, in two phases per group of 64
+// primitives.  The reference walks the list per ray; here 64 lanes walk it together with the primitive index
+// wave-uniform, so any step a single lane needs is executed by the whole wave -- and the costly steps (square root
+// and two correctly rounded divisions of a sphere that the ray's line meets, the plane's division) are needed by few lanes per
+// primitive but by SOME lane for a third of them.  Phase 1 computes, for every primitive of the group, only what
+// decides whether the reference gets past its first return: the sphere's discriminant (same operations, same order:
+// the same sign) or the plane's |denom| > EPSILON, and records it as one bit per lane and primitive.  Phase 2: each
+// lane walks ITS candidates in index order through the full test, data fetched per lane from the compact table.
+// A primitive that is no candidate cannot change t (the reference returns false for it before touching t), and
+// candidates are tested in index order with the running t, so (hit, t) are those of the sequential loop.
+__device__ __forceinline__ void prims_two_phase(const RenderParams &p, f3 o, f3 d, float &t, int &hit) {
+    typedef const __attribute__((address_space(4))) PrimCompact *scalar_ptr;
+    const float a = dot3(d, d);
+    for (int base = 0; base < p.n_prims; base += 64) {
+        const int n = (p.n_prims - base) < 64 ? (p.n_prims - base) : 64;
+        unsigned m0 = 0u, m1 = 0u;                       // candidate bits of primitives base + 0..31, base + 32..63
+        for (int k = 0; k < n; k++) {
+            const scalar_ptr q = (scalar_ptr)(p.prim_compact + base + k);
+            const float type = q->type;
+            bool cand = false;
+            if (type == 0.0f) {
+                const f3 oc = o - mk3(q->cx, q->cy, q->cz);
+                const float radius = q->radius;
+                const float b = 2.0f * dot3(d, oc);
+                const float c = dot3(oc, oc) - (radius * radius);
+                const float disc = (b * b) - ((4.0f * a) * c);
+                cand = !(disc < 0.0f);
+            } else if (type == 1.0f) {
+                cand = fabsf(dot3(mk3(q->nx, q->ny, q->nz), d)) > HPT_EPSILON;
+            }
+            const unsigned bit = 1u << (k & 31);
+            if (k < 32) m0 |= cand ? bit : 0u; else m1 |= cand ? bit : 0u;
+        }
+        while (hpt_ballot((m0 | m1) != 0u) != 0ull) {
+            if ((m0 | m1) != 0u) {
+                int k;
+                if (m0 != 0u) { k = __builtin_ctz(m0); m0 &= m0 - 1u; }
+                else { k = 32 + __builtin_ctz(m1); m1 &= m1 - 1u; }
+                const float4 *g = reinterpret_cast<const float4 *>(p.prim_compact + base + k);
+                const float4 A = g[0], B = g[1];
+                HPT_KEEP_ADDRESS(g, B.w);
+                if (intersect_prim_values(B.x, mk3(A.x, A.y, A.z), A.w, mk3(B.y, B.z, B.w), o, d, t)) hit = HPT_HIT_PRIMITIVE(base + k);
+            }
+        }
+    }
 }
 
 // ---- BVH traversal: same visits, same order, same t at every test as
@@ -648,8 +730,10 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
 __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o, f3 d) {
     s.t = 1000.0f;
     s.hit = HPT_HIT_MISS;
-    for (int i = 0; i < p.n_prims; i++)
-        if (intersect_prim(p.prims + i, o, d, s.t)) s.hit = HPT_HIT_PRIMITIVE(i);
+    if (p.n_prims >= HPT_TWO_PHASE_MIN_PRIMS) prims_two_phase(p, o, d, s.t, s.hit);
+    else
+        for (int i = 0; i < p.n_prims; i++)
+            if (intersect_prim(p.prims + i, o, d, s.t)) s.hit = HPT_HIT_PRIMITIVE(i);
     s.sp = 0;
     s.cur = HPT_REF_DONE;
     s.rd = d;

@@ -845,7 +845,10 @@ def _random_case(case):
     s = scenes.scene("random", n=n, seed=int(rng.integers(1, 1 << 20)), extent=float(rng.uniform(20, 120)),
                      size=float(rng.uniform(2, 60)), width=int(rng.integers(17, 80)), height=int(rng.integers(9, 70)))
     prims = [scenes.sphere(tuple(rng.uniform(-150, 150, 3)), float(rng.uniform(10, 60)), emissive=tuple(rng.uniform(4, 16, 3)))]
-    for _ in range(int(rng.integers(0, 6))):
+    # cases from 200 on: LONG primitive lists (the two-phase loop of the closest-hit query, render_kernels.h): 12 (the
+    # switch-over length), 31..33 and 63..65 (the candidate masks' word and group boundaries), 129 (C5's), 140
+    n_extra = int(rng.integers(0, 6)) if case < 200 else int(rng.choice([11, 12, 30, 31, 32, 62, 63, 64, 128, 139]))
+    for _ in range(n_extra):
         kind = int(rng.integers(0, 4))
         c = tuple(rng.uniform(-90, 90, 3))
         if kind == 0:
@@ -858,6 +861,14 @@ def _random_case(case):
         else:
             nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
             prims.append(scenes.plane(c, tuple(nrm), tuple(rng.uniform(0, 1, 3)), ptype=int(rng.choice([1, 1, 4]))))
+    if case >= 200:
+        # ties and degenerate discriminants: an exact duplicate of a sphere (the lower index must win), a sphere around the
+        # camera (rays start inside: the t1 branch), a grazing-size sphere (discriminant near 0), a dead type in between
+        k = int(rng.integers(1, len(prims)))
+        prims.insert(int(rng.integers(1, len(prims))), prims[k].copy())
+        prims[int(rng.integers(1, len(prims)))] = scenes.sphere((0.0, 0.0, -200.0), 400.0, diffuse=(0.5, 0.5, 0.5))
+        prims[int(rng.integers(1, len(prims)))] = scenes.sphere(tuple(rng.uniform(-30, 30, 3)), 1e-3, diffuse=(1, 0, 0))
+        prims[int(rng.integers(1, len(prims)))] = scenes.plane((0, 0, 0), (0, 1, 0), (0.3, 0.3, 0.3), ptype=7)
     mat_kind = int(rng.integers(0, 3))
     mats = scenes.make_material(tuple(rng.uniform(0, 1, 3)),
                                 specular=tuple(rng.uniform(0, 1, 3)) if mat_kind == 1 else (0, 0, 0),
@@ -910,3 +921,33 @@ def test_randomized_iterative_pipeline_bit_exact(case):
         assert np.array_equal(be.path_counts(), o.iter_px["completed"]), k
     st = be.stats()
     assert st["rays_primary"] == o.iter_st.rays_primary and st["rays_bounce"] == o.iter_st.rays_bounce
+
+
+@pytest.mark.parametrize("case", range(200, 212))
+def test_randomized_long_primitive_lists_bit_exact(case):
+    """Scenes with 13..141 analytic primitives (spheres of every material, planes of type 1, dead types, an exact
+    duplicate, a sphere around the camera, a near-zero-radius sphere): the closest-hit query walks long lists in two
+    phases (candidate bits, then each lane its candidates in index order) and must give the reference's sequential
+    result -- hit ids, t bits, radiance, ray counters -- through hpt_render, hpt_kernel_execute and the iterative calls."""
+    s, bvh, o = _random_case(case)
+    assert len(s["primitives"]) >= 12
+    be = backend_for(s, bvh)
+    hit, t = be.primary_hits(1)
+    oh, ot, _ = o.primary_hits(1)
+    assert np.array_equal(hit, oh) and mismatch(t, ot) == 0
+    img = be.kernel_execute(2)
+    oimg, cnt = o.kernel_execute(2)
+    assert mismatch(img, oimg) == 0
+    st = be.stats()
+    assert (st["rays_primary"], st["rays_bounce"], st["paths"]) == (cnt["rays_primary"], cnt["rays_bounce"], cnt["paths"])
+    d = dev_image(be)
+    be.render(0, 3, d.data_ptr()); be.synchronize()
+    assert mismatch(d.cpu().numpy(), o.render(0, 3)[0]) == 0
+    if case % 3 == 0:
+        want = np.zeros((s["width"] * s["height"], 3), np.float32)
+        d = dev_image(be)
+        be.first_bounce(); o.iter_first_bounce()
+        for _ in range(3):
+            be.bounce(); be.reconstruct_paths(d.data_ptr()); o.iter_bounce(); o.iter_reconstruct(want)
+        be.synchronize()
+        assert mismatch(d.cpu().numpy(), want) == 0

@@ -87,7 +87,9 @@ def test_host_bvh_parallel_build_is_thread_invariant(monkeypatch, name, kw, thre
 def test_obj_reader_parallel_chunks(tmp_path, monkeypatch):
     """Files over 1 MB are parsed in line-aligned chunks by several threads: interleaved `v`/`f` lines, negative
     (relative) indices, polygons, `a/b/c` tokens, comments and CRLF line ends must give what a sequential
-    parse gives, whatever the thread count; a face naming a vertex that follows it is rejected."""
+    parse gives, whatever the thread count.  A face may name a vertex that FOLLOWS it (the reference resolves indices
+    after the whole file is read, obj_reader.cpp:77-81): such a file gives the oracle reader's list; an index beyond the
+    file's vertices, or a negative one reaching before the first vertex, is rejected."""
     rng = np.random.default_rng(5)
     lines, verts, want = [], [], []
     for blk in range(4000):
@@ -117,10 +119,17 @@ def test_obj_reader_parallel_chunks(tmp_path, monkeypatch):
         monkeypatch.setenv("HPT_BUILD_THREADS", str(threads))
         got = api.load_obj(str(p))
         assert got.shape == want.shape and np.array_equal(got, want), threads
-    q = tmp_path / "fwd.obj"
-    q.write_text("v 0 0 0\nv 1 0 0\nf 1 2 3\nv 0 1 0\n" + "# padding\n" * 120000)
-    with pytest.raises(api.HptError):
-        api.load_obj(str(q))
+    for pad in (0, 120000):                                   # the sequential and the chunked path
+        q = tmp_path / ("fwd%d.obj" % pad)
+        q.write_text("f 3 1 2\nv 0 0 0\nv 1 0 0\nf 1 2 3\nv 0 1 0\nf 2 3 1\n" + "# padding\n" * pad)
+        got = api.load_obj(str(q))
+        assert np.array_equal(got, orc.load_obj(str(q))[1]) and got.shape == (9, 3)
+        q.write_text("v 0 0 0\nv 1 0 0\nf 1 2 4\nv 0 1 0\n" + "# padding\n" * pad)
+        with pytest.raises(api.HptError):
+            api.load_obj(str(q))
+        q.write_text("v 0 0 0\nf -1 -2 -1\nv 1 0 0\nv 0 1 0\n" + "# padding\n" * pad)
+        with pytest.raises(api.HptError):
+            api.load_obj(str(q))
 
 
 @pytest.mark.parametrize("san", ["thread", "address,undefined"])
@@ -331,3 +340,24 @@ def test_tile_exchange_index_math():
         img = np.random.default_rng(1).random((w * h, 3), dtype=np.float32)
         slabs = np.stack([dist.pack_tiles_np(img, w, h, r, world) for r in range(world)])
         assert np.array_equal(dist.unpack_tiles_np(slabs, w, h, world), img)
+
+
+def test_integration_forwarding_body_compiles(tmp_path):
+    """The replacement body of OpenCL_Manager printed in INTEGRATION.md (what a reference maintainer would add)
+    compiles against a declaration of the reference's nine public methods (opencl_manager.hpp:13-50, restated in
+    tests/native/ocl_decl/) and the C-ABI headers.  Boundary check only; it says nothing about parity."""
+    import re
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```cpp\n(// opencl_manager\.cpp, HIP build.*?)```", text, re.S)
+    assert m, "forwarding body not found in INTEGRATION.md"
+    body = m.group(1)
+    for method in ("initialize", "kernel_load", "new_kernel_load", "triangles_to_texture", "bvh_to_texture", "kernel_execute",
+                   "initial_ray_kernel_execute", "ray_kernel_execute", "reconstruct_kernel_execute"):
+        assert "OpenCL_Manager::%s(" % method in body, method
+    src = tmp_path / "opencl_manager_hip.cpp"
+    src.write_text(body)
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-c", str(src), "-o", str(tmp_path / "fwd.o"),
+                        "-I" + os.path.join(ROOT, "tests", "native", "ocl_decl"), "-I" + os.path.join(ROOT, "include"),
+                        "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
