@@ -98,6 +98,7 @@ struct hpt_ctx {
     int leaf_records = 0;            // HPT_LEAF_RECORDS: 0 = per tree, 1 = singles, 2 = pairs
     hpt_primitive *d_prims = nullptr;
     PrimCompact *d_prim_compact = nullptr;   // centre, radius, type, plane normal of each primitive (render_kernels.h)
+    PrimPair *d_prim_pairs = nullptr;        // the same, two primitives side by side
     int n_prims = 0;
     hpt_material *d_mats = nullptr;
     int n_mats = 0;
@@ -271,7 +272,7 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     memset(&p, 0, sizeof p);
     p.pairs = ctx->d_pairs;
     p.singles = ctx->singles ? 1 : 0;
-    p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.prim_compact = ctx->d_prim_compact; p.mats = ctx->d_mats;
+    p.nodes = ctx->d_nodes; p.tris = ctx->d_tris; p.prims = ctx->d_prims; p.prim_compact = ctx->d_prim_compact; p.prim_pairs = ctx->d_prim_pairs; p.mats = ctx->d_mats;
     p.image = d_image; p.hit_id = ctx->d_hit_id; p.hit_t = ctx->d_hit_t;
     p.work_counter = ctx->d_work; p.counters = ctx->d_counters;
     p.cam = ctx->cam;
@@ -404,8 +405,11 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     size_t lds; long blocks_max;
     size_t scratch_used = 0;
     typedef void (*render_fn)(const RenderParams);
-    const render_fn fn = ctx->count_loads ? (ctx->singles ? render_kernel<true, true> : render_kernel<false, true>)
-                                          : (ctx->singles ? render_kernel<true, false> : render_kernel<false, false>);
+    // one instantiation per (record form, counting build, long primitive list)
+    static const render_fn kRender[2][2][2] = {
+        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
+        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
+    const render_fn fn = kRender[ctx->singles ? 1 : 0][ctx->count_loads ? 1 : 0][ctx->n_prims >= HPT_TWO_PHASE_MIN_PRIMS ? 1 : 0];
     if ((rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max, noalloc, &scratch_used))) return rc;
 
     // paths (= 12-B samples) per launch: the sample buffer, and 32-bit work indices with headroom for the work
@@ -541,7 +545,7 @@ int hpt_destroy(hpt_ctx *ctx) {
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);
-    (void)hipFree(ctx->d_iter); (void)hipFree(ctx->d_pairs); (void)hipFree(ctx->d_prim_compact);
+    (void)hipFree(ctx->d_iter); (void)hipFree(ctx->d_pairs); (void)hipFree(ctx->d_prim_compact); (void)hipFree(ctx->d_prim_pairs);
     for (hipEvent_t ev : ctx->ev_render) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->ev_iter) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->ev_recon) if (ev) (void)hipEventDestroy(ev);
@@ -676,6 +680,18 @@ int hpt_set_scene(hpt_ctx *ctx, const hpt_primitive *primitives, int n_primitive
         compact[i] = PrimCompact{q.center.x, q.center.y, q.center.z, q.radius, q.type.x, q.plane_normal.x, q.plane_normal.y, q.plane_normal.z};
     }
     if ((rc = replace_buffer(ctx, ctx->d_prim_compact, compact.data(), compact.size() * sizeof(PrimCompact)))) return rc;
+    std::vector<PrimPair> pairs(((size_t)n_primitives + 1) / 2);
+    for (size_t j = 0; j < pairs.size(); j++)
+        for (int h = 0; h < 2; h++) {
+            PrimPair &pp = pairs[j];
+            const size_t i = 2 * j + (size_t)h;
+            if (i >= (size_t)n_primitives) { pp.cx[h] = pp.cy[h] = pp.cz[h] = pp.rr[h] = pp.nx[h] = pp.ny[h] = pp.nz[h] = 0.0f; pp.type[h] = -1.0f; continue; }
+            const PrimCompact &c = compact[i];
+            const volatile float r = c.radius;            // one fp32 multiply, rounded once (no contraction, no excess precision)
+            const volatile float rr = r * r;
+            pp.cx[h] = c.cx; pp.cy[h] = c.cy; pp.cz[h] = c.cz; pp.rr[h] = rr; pp.type[h] = c.type; pp.nx[h] = c.nx; pp.ny[h] = c.ny; pp.nz[h] = c.nz;
+        }
+    if ((rc = replace_buffer(ctx, ctx->d_prim_pairs, pairs.data(), pairs.size() * sizeof(PrimPair)))) return rc;
     if ((rc = replace_buffer(ctx, ctx->d_mats, materials, (size_t)n_materials * sizeof(hpt_material)))) return rc;
     ctx->n_prims = n_primitives; ctx->n_mats = n_materials;
     return HPT_OK;
@@ -760,8 +776,12 @@ static int iter_launch_params(hpt_ctx *ctx, RenderParams &p, unsigned &blocks) {
 
 // traversal half of a call: persistent iter_trace_kernel over this shard's pixel slots
 static int iter_trace(hpt_ctx *ctx, RenderParams &p, int first) {
+    typedef void (*trace_fn)(const RenderParams, const IterState, int);
+    static const trace_fn kTrace[2][2] = {{iter_trace_kernel<false, false>, iter_trace_kernel<false, true>},
+                                          {iter_trace_kernel<true, false>, iter_trace_kernel<true, true>}};
+    const trace_fn fn = kTrace[ctx->singles ? 1 : 0][ctx->n_prims >= HPT_TWO_PHASE_MIN_PRIMS ? 1 : 0];
     size_t lds; long blocks_max;
-    int rc = prepare_persistent(ctx, ctx->singles ? (const void *)iter_trace_kernel<true> : (const void *)iter_trace_kernel<false>, p, lds, blocks_max);
+    int rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max);
     if (rc) return rc;
     long blocks = blocks_max;
     long need = ((long)p.n_slots + kBlock - 1) / kBlock;
@@ -769,8 +789,7 @@ static int iter_trace(hpt_ctx *ctx, RenderParams &p, int first) {
     p.spill_stride = (uint32_t)(blocks * kBlock);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(unsigned int), ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_iter[0], ctx->stream));
-    if (ctx->singles) hipLaunchKernelGGL(iter_trace_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
-    else hipLaunchKernelGGL(iter_trace_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(kBlock), lds, ctx->stream, p, ctx->iter, first);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_iter[1], ctx->stream));
     return HPT_OK;

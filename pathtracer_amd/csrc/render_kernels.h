@@ -39,6 +39,7 @@ struct RenderParams {
                                      // (singles != 0); leaf references point here
     const hpt_primitive *prims;
     const struct PrimCompact *prim_compact;   // the fields the closest-hit query reads of each primitive, 32 B each (long lists: two-phase loop)
+    const struct PrimPair *prim_pairs;        // the same for primitives 2j, 2j+1 side by side: phase 1 tests two spheres per packed instruction
     const hpt_material *mats;
     float *image;                    // width*height*3
     int32_t *hit_id;                 // primary_hits only
@@ -82,6 +83,10 @@ struct Ray { f3 o, d; };
 // What intersect() reads of a primitive (ray_kernel.cl:524-602): centre, radius, type, plane normal.  Built by
 // hpt_set_scene beside the wire-format array; 32 B = one s_load_dwordx8 (wave-uniform index) or two 16-B lane-loads.
 struct __attribute__((aligned(32))) PrimCompact { float cx, cy, cz, radius, type, nx, ny, nz; };
+// Primitives 2j and 2j+1 with each field as a register pair (phase 1 of prims_two_phase on packed fp32).  rr = radius *
+// radius, rounded to fp32 on the host exactly as the device rounds it (one IEEE multiply).  An odd list ends in a
+// primitive of type -1 (never hit, never a candidate).
+struct __attribute__((aligned(64))) PrimPair { float cx[2], cy[2], cz[2], rr[2], type[2], nx[2], ny[2], nz[2]; };
 #define HPT_TWO_PHASE_MIN_PRIMS 12   // shorter lists walk the wire-format array directly (one pass, no candidate masks)
 
 // ---- camera ray: initial_ray_kernel.cl:859-883 (== pathtracer_kernel.cl:912-937) ----
@@ -344,28 +349,71 @@ __device__ __forceinline__ bool intersect_prim_values(float type, f3 center, flo
 // lane walks ITS candidates in index order through the full test, data fetched per lane from the compact table.
 // A primitive that is no candidate cannot change t (the reference returns false for it before touching t), and
 // candidates are tested in index order with the running t, so (hit, t) are those of the sequential loop.
+// Phase 1 for two spheres at once: the discriminants of primitives 2j (low halves) and 2j+1 (high halves).  Per half
+// the operations and their order are those of the scalar form -- oc = o - c; b = 2 * ((dx*ocx + dy*ocy) + dz*ocz);
+// c = ((ocx*ocx + ocy*ocy) + ocz*ocz) - r*r; disc = b*b - (4a)*c -- as v_pk_add_f32 / v_pk_mul_f32 (IEEE per component,
+// no contraction); the ray's components are broadcast from register pairs with op_sel, the spheres' come as SGPR pairs.
+__device__ __forceinline__ hpt_v2f sphere_pair_disc(hpt_v2f oxy, hpt_v2f ozdx, hpt_v2f dyz, hpt_v2f a4,
+                                                    hpt_v2f cx, hpt_v2f cy, hpt_v2f cz, hpt_v2f rr) {
+    hpt_v2f ocx, ocy, ocz, u, v, w;
+    asm("v_pk_add_f32 %0, %6, %10 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // ocx = o.x - cx
+        "v_pk_add_f32 %1, %6, %11 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // ocy = o.y - cy
+        "v_pk_add_f32 %2, %7, %12 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // ocz = o.z - cz
+        "v_pk_mul_f32 %3, %7, %0 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                               // u = d.x * ocx
+        "v_pk_mul_f32 %4, %8, %1 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                               // v = d.y * ocy
+        "v_pk_mul_f32 %5, %0, %0\n\t"                                                           // w = ocx * ocx
+        "v_pk_mul_f32 %0, %1, %1\n\t"                                                           // ocx <- ocy * ocy
+        "v_pk_add_f32 %3, %3, %4\n\t"                                                           // u = dx*ocx + dy*ocy
+        "v_pk_mul_f32 %4, %8, %2 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                               // v = d.z * ocz
+        "v_pk_add_f32 %5, %5, %0\n\t"                                                           // w = ocx^2 + ocy^2
+        "v_pk_mul_f32 %0, %2, %2\n\t"                                                           // ocx <- ocz * ocz
+        "v_pk_add_f32 %3, %3, %4\n\t"                                                           // u = dot(d, oc)
+        "v_pk_add_f32 %5, %5, %0\n\t"                                                           // w = dot(oc, oc)
+        "v_pk_add_f32 %3, %3, %3\n\t"                                                           // b = 2 * dot(d, oc)
+        "v_pk_add_f32 %5, %5, %13 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                 // c = dot(oc, oc) - r*r
+        "v_pk_mul_f32 %3, %3, %3\n\t"                                                           // b * b
+        "v_pk_mul_f32 %5, %9, %5\n\t"                                                           // (4a) * c
+        "v_pk_add_f32 %3, %3, %5 neg_lo:[0,1] neg_hi:[0,1]"                                      // disc
+        : "=&v"(ocx), "=&v"(ocy), "=&v"(ocz), "=&v"(u), "=&v"(v), "=&v"(w)
+        : "v"(oxy), "v"(ozdx), "v"(dyz), "v"(a4), "s"(cx), "s"(cy), "s"(cz), "s"(rr));
+    return u;
+}
+
+__device__ __forceinline__ bool prim_candidate(float type, float cx, float cy, float cz, float rr, float nx, float ny, float nz,
+                                               f3 o, f3 d, float a) {
+    if (type == 0.0f) {
+        const f3 oc = o - mk3(cx, cy, cz);
+        const float b = 2.0f * dot3(d, oc);
+        const float c = dot3(oc, oc) - rr;
+        const float disc = (b * b) - ((4.0f * a) * c);
+        return !(disc < 0.0f);
+    }
+    if (type == 1.0f) return fabsf(dot3(mk3(nx, ny, nz), d)) > HPT_EPSILON;
+    return false;
+}
+
 __device__ __forceinline__ void prims_two_phase(const RenderParams &p, f3 o, f3 d, float &t, int &hit) {
-    typedef const __attribute__((address_space(4))) PrimCompact *scalar_ptr;
+    typedef const __attribute__((address_space(4))) PrimPair *scalar_ptr;
     const float a = dot3(d, d);
+    const float a4s = 4.0f * a;
+    const hpt_v2f oxy = hpt_v2f{o.x, o.y}, ozdx = hpt_v2f{o.z, d.x}, dyz = hpt_v2f{d.y, d.z}, a4 = hpt_v2f{a4s, a4s};
     for (int base = 0; base < p.n_prims; base += 64) {
         const int n = (p.n_prims - base) < 64 ? (p.n_prims - base) : 64;
         unsigned m0 = 0u, m1 = 0u;                       // candidate bits of primitives base + 0..31, base + 32..63
-        for (int k = 0; k < n; k++) {
-            const scalar_ptr q = (scalar_ptr)(p.prim_compact + base + k);
-            const float type = q->type;
-            bool cand = false;
-            if (type == 0.0f) {
-                const f3 oc = o - mk3(q->cx, q->cy, q->cz);
-                const float radius = q->radius;
-                const float b = 2.0f * dot3(d, oc);
-                const float c = dot3(oc, oc) - (radius * radius);
-                const float disc = (b * b) - ((4.0f * a) * c);
-                cand = !(disc < 0.0f);
-            } else if (type == 1.0f) {
-                cand = fabsf(dot3(mk3(q->nx, q->ny, q->nz), d)) > HPT_EPSILON;
+        for (int k = 0; k < n; k += 2) {                 // primitives base + k, base + k + 1 (the pair (base + k) / 2)
+            const scalar_ptr q = (scalar_ptr)(p.prim_pairs + ((base + k) >> 1));
+            const float ty0 = q->type[0], ty1 = q->type[1];
+            bool c0, c1;
+            if (ty0 == 0.0f && ty1 == 0.0f) {            // (wave-uniform) two spheres: packed
+                const hpt_v2f disc = sphere_pair_disc(oxy, ozdx, dyz, a4, hpt_v2f{q->cx[0], q->cx[1]}, hpt_v2f{q->cy[0], q->cy[1]},
+                                                      hpt_v2f{q->cz[0], q->cz[1]}, hpt_v2f{q->rr[0], q->rr[1]});
+                c0 = !(disc.x < 0.0f); c1 = !(disc.y < 0.0f);
+            } else {
+                c0 = prim_candidate(ty0, q->cx[0], q->cy[0], q->cz[0], q->rr[0], q->nx[0], q->ny[0], q->nz[0], o, d, a);
+                c1 = prim_candidate(ty1, q->cx[1], q->cy[1], q->cz[1], q->rr[1], q->nx[1], q->ny[1], q->nz[1], o, d, a);
             }
-            const unsigned bit = 1u << (k & 31);
-            if (k < 32) m0 |= cand ? bit : 0u; else m1 |= cand ? bit : 0u;
+            const unsigned bits = (c0 ? 1u : 0u) | (c1 ? 2u : 0u);
+            if (k < 32) m0 |= bits << (k & 31); else m1 |= bits << (k & 31);
         }
         while (hpt_ballot((m0 | m1) != 0u) != 0ull) {
             if ((m0 | m1) != 0u) {
@@ -727,10 +775,13 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
 
 // Starts the closest-hit query of ray (o, d): primitives first, then the tree (ray_kernel.cl:726-745).
 // Leaves cur = root reference, or HPT_REF_DONE when the root box is missed / there is no tree.
+// LONG: the kernel instantiation for long primitive lists (>= HPT_TWO_PHASE_MIN_PRIMS; chosen by the host per scene),
+// which walks them in two phases; the other instantiation does not carry that code at all.
+template <bool LONG>
 __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o, f3 d) {
     s.t = 1000.0f;
     s.hit = HPT_HIT_MISS;
-    if (p.n_prims >= HPT_TWO_PHASE_MIN_PRIMS) prims_two_phase(p, o, d, s.t, s.hit);
+    if (LONG) prims_two_phase(p, o, d, s.t, s.hit);
     else
         for (int i = 0; i < p.n_prims; i++)
             if (intersect_prim(p.prims + i, o, d, s.t)) s.hit = HPT_HIT_PRIMITIVE(i);
@@ -772,7 +823,7 @@ __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o,
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 6
 #endif
-template <bool SINGLES, bool COUNT>
+template <bool SINGLES, bool COUNT, bool LONG>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
@@ -873,7 +924,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const Render
                         color = mk3(0, 0, 0); weight = mk3(1, 1, 1);
                         b = 0;
                     }
-                    trav_start(p, tv, r.o, r.d);
+                    trav_start<LONG>(p, tv, r.o, r.d);
                 }
             }
         } else if (nT > nN) {
@@ -950,7 +1001,7 @@ struct IterState {
 // steps of render_kernel and stores (hit, t).  first != 0: the ray is the camera ray of jitter cell 0, which
 // is generated here and left in cur_a/cur_b (origin, direction) and cur_d.x (rng counter after the jitter).
 // Pixels whose cached bounce already ended the path trace nothing.
-template <bool SINGLES>
+template <bool SINGLES, bool LONG>
 __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const RenderParams p, const IterState it, int first) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
@@ -1011,7 +1062,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const Re
                     o = mk3(a.x, a.y, a.z); d = mk3(b.x, b.y, b.z);
                 }
                 traced++;
-                trav_start(p, tv, o, d);
+                trav_start<LONG>(p, tv, o, d);
             }
         } else if (nT > nN) {
             trav_tri_steps<SINGLES, false>(p, tv, stack, stride, spill, nT, n_loads);
