@@ -823,8 +823,13 @@ __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o,
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 6
 #endif
+#ifdef HPT_MAX_SGPRS                 // development: cap the SGPRs (the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16)) blocks of 256 per CU)
+#define HPT_SGPR_CAP __attribute__((amdgpu_num_sgpr(HPT_MAX_SGPRS)))
+#else
+#define HPT_SGPR_CAP
+#endif
 template <bool SINGLES, bool COUNT, bool LONG>
-__global__ void __launch_bounds__(256, HPT_MIN_WAVES) render_kernel(const RenderParams p) {
+__global__ void __launch_bounds__(256, HPT_MIN_WAVES) HPT_SGPR_CAP render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;   // per WAVE (from ballots: scalar registers, not three per lane)
