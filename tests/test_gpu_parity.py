@@ -205,6 +205,13 @@ def test_sample_buffer_batches(monkeypatch):
     assert mismatch(d.cpu().numpy(), o.render(0, 23)[0]) == 0
     st = be.stats()
     assert st["paths"] == 23 * 96 * 96
+    assert st["launches"] > 1
+    # a render so long that not even one tile's iterations fit: one tile at a time, iterations in batches
+    s2, bvh2, o2 = get_scene("cornell", width=16, height=24)
+    be2 = backend_for(s2, bvh2)
+    d2 = dev_image(be2)
+    be2.render(0, 1500, d2.data_ptr()); be2.render(1500, 1503, d2.data_ptr()); be2.synchronize()
+    assert mismatch(d2.cpu().numpy(), o2.render(0, 1503)[0]) == 0
 
 
 @pytest.mark.parametrize("w,h,world", [(64, 64, 2), (100, 52, 3), (72, 40, 8)])
