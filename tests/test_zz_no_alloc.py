@@ -88,3 +88,32 @@ def test_noalloc_argument_errors():
     be.upload_triangles(bvh["triangles"][:5])             # leaves now point past the triangle array
     with pytest.raises(api.HptError, match="triangles are uploaded"):
         be.render_noalloc(0, 1, d.data_ptr())
+
+
+def test_noalloc_captures_into_a_hip_graph():
+    """What the entry point is for: under HIP graph capture nothing may allocate or synchronise.  hpt_render_noalloc on
+    a capturing stream records only memsets and kernel launches, so the capture succeeds (hpt_render's first use, which
+    allocates and records events, invalidates one), and every replay of the graph renders the same image bit for bit."""
+    s, bvh, _ = get_scene("cornell", width=128, height=128)
+    be = api.Backend(128, 128)
+    be.load(s, bvh)
+    n = 128 * 128 * 3
+    want = torch.zeros(n, dtype=torch.float32, device="cuda")
+    be.render(0, 6, want.data_ptr()); be.synchronize()
+    d = torch.zeros(n, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    be.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        be.render_noalloc(0, 6, d.data_ptr())             # outside capture once: kernel attributes and occupancy get cached
+    stream.synchronize()
+    assert torch.equal(d.view(torch.int32), want.view(torch.int32))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        be.render_noalloc(0, 6, d.data_ptr())
+    for _ in range(2):
+        d.fill_(-3.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d.view(torch.int32), want.view(torch.int32))
+    be.set_stream(0)
