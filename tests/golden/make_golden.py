@@ -46,6 +46,13 @@ def main():
     img, cnt = o.render(0, 4, n_threads=1)
     np.savez_compressed(os.path.join(HERE, "cornell_32_radiance_4spp.npz"), bits=bits(img),
                         counters=np.array([cnt[k] for k in sorted(cnt)], np.int64), counter_names=np.array(sorted(cnt)))
+    # C5's material and primitive mix (glossy triangles, 64 mirror and 64 glass spheres) at a reduced frame: radiance of
+    # 3 samples through every shading branch, plus the closest hits of iteration 0 (primitive ids included)
+    s, bvh, o = get_scene("glossy", width=48, height=27)
+    img, cnt = o.render(0, 3, n_threads=1)
+    hit, t, _ = o.primary_hits(0)
+    np.savez_compressed(os.path.join(HERE, "glossy_48x27_radiance_3spp.npz"), bits=bits(img), hit_0=hit, tbits_0=bits(t),
+                        counters=np.array([cnt[k] for k in sorted(cnt)], np.int64), counter_names=np.array(sorted(cnt)))
     print("wrote", sorted(os.listdir(HERE)))
 
 

@@ -67,6 +67,34 @@ def test_radiance_sample_bit_exact(name, kw):
         assert (st["rays_primary"], st["rays_bounce"], st["paths"]) == (cnt["rays_primary"], cnt["rays_bounce"], cnt["paths"])
 
 
+def test_hip_path_against_committed_golden_vectors():
+    """The committed fixtures of tests/golden/ (made by make_golden.py from the oracle; the reference holds none) against
+    the HIP path directly: primary hits of two scenes, radiance of the Cornell scene, and C5's scene content."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    for name, kw, iters in [("cornell", dict(width=64, height=64), (0, 7)), ("random", dict(n=2000, seed=1, width=64, height=64), (0, 41))]:
+        g = np.load(os.path.join(gold, "%s_64_primary.npz" % name))
+        s, bvh, _ = get_scene(name, **kw)
+        be = backend_for(s, bvh)
+        for it in iters:
+            hit, t = be.primary_hits(it)
+            assert np.array_equal(hit, g["hit_%d" % it]) and np.array_equal(bits(t), g["tbits_%d" % it])
+    for fixture, name, kw, spp in [("cornell_32_radiance_4spp", "cornell", dict(width=32, height=32), 4),
+                                   ("glossy_48x27_radiance_3spp", "glossy", dict(width=48, height=27), 3)]:
+        g = np.load(os.path.join(gold, fixture + ".npz"))
+        s, bvh, _ = get_scene(name, **kw)
+        be = backend_for(s, bvh)
+        d = dev_image(be)
+        be.render(0, spp, d.data_ptr()); be.synchronize()
+        assert np.array_equal(bits(d.cpu().numpy()), g["bits"].reshape(-1))
+        st = be.stats()
+        cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+        assert (st["rays_primary"], st["rays_bounce"], st["paths"]) == (cnt["rays_primary"], cnt["rays_bounce"], cnt["paths"])
+        if "hit_0" in g.files:
+            hit, t = be.primary_hits(0)
+            assert np.array_equal(hit, g["hit_0"]) and np.array_equal(bits(t), g["tbits_0"])
+
+
 def test_glossy_and_refractive_materials_bit_exact():
     """Triangle material with specular + IOR (the C5 material) and a transmissive triangle material."""
     for spec, ior, trans in [((0.7, 0.7, 0.2), 1.9, False), ((0, 0, 0), 1.5, True)]:

@@ -260,6 +260,18 @@ def test_golden_radiance():
     assert [cnt[k] for k in sorted(cnt)] == list(g["counters"])
 
 
+def test_golden_radiance_glossy():
+    """C5's scene content (glossy triangle material, 64 mirror + 64 glass sphere primitives) at 48x27."""
+    g = np.load(os.path.join(GOLD, "glossy_48x27_radiance_3spp.npz"))
+    s, bvh, o = get_scene("glossy", width=48, height=27)
+    img, cnt = o.render(0, 3, n_threads=2)
+    assert np.array_equal(bits(img), g["bits"])
+    assert [cnt[k] for k in sorted(cnt)] == list(g["counters"])
+    hit, t, _ = o.primary_hits(0)
+    assert np.array_equal(hit, g["hit_0"]) and np.array_equal(bits(t), g["tbits_0"])
+    assert (g["hit_0"] <= -3).sum() > 20 and (g["hit_0"] >= 0).sum() > 200      # spheres and triangles are both hit
+
+
 def test_oracle_brute_force_closest_hit():
     """The traversal order never changes WHICH hit is closest unless two hits tie: compare with an
     O(n) loop over all triangles where the minimum is unique."""
