@@ -135,6 +135,15 @@ int hpt_render_sample(hpt_ctx *ctx, int iteration, float *image_rgb);
  * hpt_render_sample.  Asynchronous on the context's stream. */
 int hpt_render(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image);
 
+/* Device images for callers without the HIP runtime API (plain C, another language's FFI): hpt_image_alloc gives a
+ * zero-filled width*height*3 float image on the context's device for hpt_render / hpt_reconstruct_paths,
+ * hpt_read_image copies one to the host in stream order and waits, hpt_image_free releases it.  The reference
+ * keeps the image on the host and copies it both ways on every call (opencl_manager.cpp:576-648); SURVEY.md 8b
+ * lists hpt_read_image for the device-resident form. */
+int hpt_image_alloc(hpt_ctx *ctx, float **d_image);
+int hpt_image_free(hpt_ctx *ctx, float *d_image);
+int hpt_read_image(hpt_ctx *ctx, const float *d_image, float *image_rgb);
+
 /* hpt_render for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  NO counterpart in the reference: its kernel_execute creates and destroys every buffer per call
  * (opencl_manager.cpp:576-604).  Same arguments, same image bit for bit as hpt_render.  Where hpt_render keeps a

@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = [
     "hpt_reconstruct", "hpt_render_sample", "hpt_render", "hpt_primary_hits", "hpt_slab_floats", "hpt_pack_tiles",
     "hpt_unpack_tiles", "hpt_tonemap", "hpt_synchronize", "hpt_get_stats",
     "hpt_first_bounce", "hpt_bounce", "hpt_reconstruct_paths", "hpt_path_counts",
-    "hpt_render_noalloc", "hpt_noalloc_scratch_bytes",
+    "hpt_render_noalloc", "hpt_noalloc_scratch_bytes", "hpt_image_alloc", "hpt_image_free", "hpt_read_image",
 ]
 
 
@@ -63,6 +63,10 @@ def lib():
         if not os.environ.get("HPT_LIB") or hasattr(L, "hpt_render_noalloc"):     # (HPT_LIB: A/B against older builds)
             L.hpt_render_noalloc.argtypes = [vp, i32, i32, vp]
             L.hpt_noalloc_scratch_bytes.argtypes = []; L.hpt_noalloc_scratch_bytes.restype = C.c_int64
+        if not os.environ.get("HPT_LIB") or hasattr(L, "hpt_image_alloc"):
+            L.hpt_image_alloc.argtypes = [vp, C.POINTER(vp)]
+            L.hpt_image_free.argtypes = [vp, vp]
+            L.hpt_read_image.argtypes = [vp, vp, vp]
         L.hpt_primary_hits.argtypes = [vp, i32, vp, vp]
         L.hpt_slab_floats.argtypes = [vp]; L.hpt_slab_floats.restype = C.c_int64
         L.hpt_pack_tiles.argtypes = [vp, vp, vp]
@@ -214,6 +218,20 @@ class Backend:
 
     def render(self, spp_begin, spp_end, d_image):
         self._chk(self.L.hpt_render(self.h, spp_begin, spp_end, C.c_void_p(d_image)))
+
+    def image_alloc(self):
+        """-> device address of a zero-filled width*height*3 float image (hpt_image_alloc)."""
+        d = C.c_void_p()
+        self._chk(self.L.hpt_image_alloc(self.h, C.byref(d)))
+        return d.value
+
+    def image_free(self, d_image):
+        self._chk(self.L.hpt_image_free(self.h, C.c_void_p(d_image)))
+
+    def read_image(self, d_image):
+        img = np.empty((self.height * self.width, 3), np.float32)
+        self._chk(self.L.hpt_read_image(self.h, C.c_void_p(d_image), _p(img)))
+        return img
 
     def render_noalloc(self, spp_begin, spp_end, d_image):
         """hpt_render for callers that cannot allocate: works in the library's static 128-MiB device array."""

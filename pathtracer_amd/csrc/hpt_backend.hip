@@ -129,7 +129,7 @@ struct hpt_ctx {
     int tris_per_trip = 8;
     int node_repeat_min = 24;
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
-    int tail_chunks = 2;             // the last tail_chunks x waves x fetch_chunk work items of a launch are reserved 64 at a time (HPT_TAIL_CHUNKS)
+    int tail_chunks = 4;             // the last tail_chunks x waves x fetch_chunk work items of a launch are reserved 64 at a time (HPT_TAIL_CHUNKS; 2/4/8/16: 701.8/700.7/700.5/700.6 ms at C3)
     int fetch_threshold = 32;        // iter_trace_kernel's FETCH step threshold (HPT_FETCH_THRESHOLD overrides)
     int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
@@ -723,6 +723,38 @@ int hpt_render(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image) {
     if (!d_image || spp_begin < 0 || spp_end < spp_begin) return fail(ctx, HPT_ERR_INVALID, "bad render range [%d,%d)", spp_begin, spp_end);
     if (spp_end == spp_begin) return HPT_OK;
     return launch_render(ctx, d_image, spp_begin, spp_end, 0);
+}
+
+int hpt_image_alloc(hpt_ctx *ctx, float **d_image) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image) return fail(ctx, HPT_ERR_INVALID, "bad image_alloc arguments");
+    *d_image = nullptr;
+    const size_t bytes = (size_t)ctx->width * ctx->height * 3 * sizeof(float);
+    float *ptr = nullptr;
+    HIP_ALLOC(ctx, &ptr, bytes);
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(ptr); return fail(ctx, HPT_ERR_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    *d_image = ptr;
+    return HPT_OK;
+}
+
+int hpt_image_free(hpt_ctx *ctx, float *d_image) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image) return HPT_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // work that still writes it
+    HIP_TRY(ctx, hipFree(d_image));
+    return HPT_OK;
+}
+
+int hpt_read_image(hpt_ctx *ctx, const float *d_image, float *image_rgb) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_image || !image_rgb) return fail(ctx, HPT_ERR_INVALID, "bad read_image arguments");
+    HIP_TRY(ctx, hipMemcpyAsync(image_rgb, d_image, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return HPT_OK;
 }
 
 int hpt_render_noalloc(hpt_ctx *ctx, int spp_begin, int spp_end, float *d_image) {

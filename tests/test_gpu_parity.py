@@ -95,6 +95,22 @@ def test_hip_path_against_committed_golden_vectors():
             assert np.array_equal(hit, g["hit_0"]) and np.array_equal(bits(t), g["tbits_0"])
 
 
+def test_device_image_helpers_without_the_hip_api():
+    """hpt_image_alloc / hpt_read_image / hpt_image_free: the device-resident batched path for a caller that has only
+    the C-ABI (no torch, no HIP runtime calls of its own)."""
+    s, bvh, o = get_scene("cornell", width=64, height=48)
+    be = backend_for(s, bvh)
+    d = be.image_alloc()
+    assert not be.read_image(d).any()                                    # zero-filled
+    be.render(0, 3, d); be.render(3, 5, d)
+    assert mismatch(be.read_image(d), o.render(0, 5)[0]) == 0
+    be.first_bounce(); be.bounce(); be.reconstruct_paths(d)
+    be.image_free(d)
+    be.image_free(0)                                                     # NULL is a no-op
+    with pytest.raises(api.HptError, match="read_image"):
+        be.read_image(0)
+
+
 def test_glossy_and_refractive_materials_bit_exact():
     """Triangle material with specular + IOR (the C5 material) and a transmissive triangle material."""
     for spec, ior, trans in [((0.7, 0.7, 0.2), 1.9, False), ((0, 0, 0), 1.5, True)]:
