@@ -67,6 +67,26 @@ __global__ void coop_lds(const float4 *__restrict__ tab, unsigned mask, int iter
     out[gl] = acc;
 }
 
+
+// Which lanes does the L1 coalesce?  Two lanes that differ in bit D of the lane id read the two halves of... the same
+// 64-B line (quarters 0 and 1); D = 1: neighbours (same quad), 4: neighbouring quads, 16 / 32: far apart.
+// same = 1: both read the SAME 16 bytes.
+__global__ void pairdist(const float4 *__restrict__ tab, unsigned mask, unsigned D, int same, int iters, float *out) {
+    unsigned gl = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned grp = gl & ~D, sub = same ? 0u : ((gl & D) ? 1u : 0u);
+    unsigned state = grp * 2654435761u + 12345u;
+    float acc = 0;
+    for (int i = 0; i < iters; i++) {
+        unsigned s0 = state * 1664525u + 1013904223u, s1 = s0 * 1664525u + 1013904223u;
+        unsigned s2 = s1 * 1664525u + 1013904223u, s3 = s2 * 1664525u + 1013904223u;
+        state = s3;
+        float4 a = tab[(size_t)((s0 >> 8) & mask) * 4 + sub], b = tab[(size_t)((s1 >> 8) & mask) * 4 + sub];
+        float4 c = tab[(size_t)((s2 >> 8) & mask) * 4 + sub], d = tab[(size_t)((s3 >> 8) & mask) * 4 + sub];
+        acc += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w)) + ((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w));
+    }
+    out[gl] = acc;
+}
+
 template <int G> static float run(const float4 *tab, unsigned mask, int active, int iters, float *out, int blocks, int threads, hipEvent_t e0, hipEvent_t e1) {
     float ms = 0;
     for (int rep = 0; rep < 2; rep++) {
@@ -102,6 +122,20 @@ int main() {
                 double clk = ms * 1e-3 * 2.4e9;
                 printf("table %5u KB G %2d active %2d: %8.3f ms  %5.1f clk/CU per wave-instr  %.2f lane-loads/clk/CU  %.1f B/clk/CU\n",
                        n_lines / 16, G, active, ms, clk / (winstr / 256), winstr * active / 256 / clk, winstr * active / 256 / clk * 16);
+            }
+        for (int same = 0; same < 2; same++)
+            for (unsigned D = 1; D <= 32; D *= 2) {
+                float ms = 0;
+                for (int rep = 0; rep < 2; rep++) {
+                    CK(hipEventRecord(e0));
+                    pairdist<<<blocks, threads>>>(tab, n_lines - 1, D, same, rep ? iters : 10, out);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                }
+                double winstr = (double)blocks * threads / 64 * iters * 4;
+                double clk = ms * 1e-3 * 2.4e9;
+                printf("table %5u KB pairs of lanes %2u apart on one line (%s): %8.3f ms  %5.1f clk/CU per wave-instr  %.2f lane-loads/clk/CU\n",
+                       n_lines / 16, D, same ? "same 16 B" : "adjacent 16 B", ms, clk / (winstr / 256), winstr * 64 / 256 / clk);
             }
         {
             float ms = 0;

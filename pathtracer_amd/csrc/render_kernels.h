@@ -11,6 +11,7 @@
 // work counter.  Results are bit-identical to the oracle's reference-order
 // traversal (argument in DESIGN.md §Traversal equivalence).
 #pragma once
+#include <type_traits>
 #include "device_math.h"
 #include "../../include/hpt/types.h"
 
@@ -736,9 +737,18 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
             const int first = __builtin_amdgcn_readfirstlane(in ? s.cur : -1);     // value of the first ACTIVE lane
             const bool uni = act != 0ull && hpt_ballot(in && s.cur != first) == 0ull && in;
             const unsigned long long U = hpt_ballot(uni);
+            // lanes that are the first of their quad at their node: the 64-B lines the L1 looks up (it merges the
+            // lanes of a quad that read one line, profiles/r02/coop_fetch/gather_coop.txt)
+            const int mine = in ? s.cur : -1 - (int)(threadIdx.x & 3u);
+            const unsigned qk = threadIdx.x & 3u;
+            const int c0 = __builtin_amdgcn_mov_dpp(mine, 0x00, 0xf, 0xf, true), c1 = __builtin_amdgcn_mov_dpp(mine, 0x55, 0xf, 0xf, true);
+            const int c2 = __builtin_amdgcn_mov_dpp(mine, 0xaa, 0xf, 0xf, true);
+            const bool leader = in && !(qk > 0u && c0 == mine) && !(qk > 1u && c1 == mine) && !(qk > 2u && c2 == mine);
+            const unsigned long long Lq = hpt_ballot(leader);
             if (act != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(act)) {
                 atomicAdd(p.counters + 11, 1ull); atomicAdd(p.counters + 13, (unsigned long long)__popcll(act));
-                if (U != 0ull) { atomicAdd(p.counters + 12, 1ull); atomicAdd(p.counters + 14, (unsigned long long)__popcll(act)); }
+                if (U != 0ull) atomicAdd(p.counters + 12, 1ull);
+                atomicAdd(p.counters + 14, (unsigned long long)__popcll(Lq));
             }
         }
 #endif
@@ -800,6 +810,55 @@ __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o,
                            o, inv, nx, ny, nz, tm);
         if (ok && tm < s.t) s.cur = p.root_ref;
     }
+}
+
+// Re-grouping at the SHADE -> trav_start hand-off.  The vector L1 merges the lanes of a QUAD that read one 64-B
+// line into one tag lookup (not lanes further apart: profiles/r02/coop_fetch/gather_coop.txt), so rays that walk the
+// same nodes at the same time are cheaper when they sit in one quad.  The paths that start a ray in this step
+// (`moving`: their traversal stack is empty, their whole state is the 16 registers below) are dealt out again
+// among the lanes they occupy: camera rays first, in their pixel order, then the bounce rays by direction octant
+// (same octant = same near/far child at every node), and the places are taken quads with four moving lanes first,
+// then three, ..., so that runs of one octant fill whole quads.  Which lane computes a path does not enter its
+// result (the RNG is keyed by path, the sample slot travels with it), so images stay bit-identical.
+// C3: distinct nodes per quad / lane-visits 0.928 -> 0.827, 88.4 -> 86.3 ms at 32 spp (profiles/r02_tuning.md).
+__device__ __forceinline__ void regroup_starting(bool moving, unsigned lane, Ray &r, int &b, unsigned &out_idx,
+                                                 uint32_t &key, uint32_t &ctr, f3 &color, f3 &weight) {
+    const unsigned long long Mv = hpt_ballot(moving);
+    // stable counting sort of the rays: key 0 camera ray, 1..8 octant of a bounce ray
+    const unsigned sk = !moving ? 99u : (b == 0 ? 0u : 1u + ((r.d.x < 0.0f ? 1u : 0u) | (r.d.y < 0.0f ? 2u : 0u) | (r.d.z < 0.0f ? 4u : 0u)));
+    unsigned rank = 0, n_moving = 0;
+    for (unsigned k = 0; k < 9u; k++) {
+        const unsigned long long B = hpt_ballot(sk == k);
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(B >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B, 0u));
+        if (sk == k) rank = n_moving + below;
+        n_moving += (unsigned)__popcll(B);
+    }
+    // order of the places: by the number of moving lanes in the quad, then by lane
+    const unsigned qn = (unsigned)__popcll((Mv >> (lane & 60u)) & 15ull);
+    unsigned place = 0, n_placed = 0;
+    for (unsigned c = 4u; c >= 1u; c--) {
+        const unsigned long long B = hpt_ballot(moving && qn == c);
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(B >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B, 0u));
+        if (qn == c) place = n_placed + below;
+        n_placed += (unsigned)__popcll(B);
+    }
+    // lane j < n_moving learns which lane holds the ray of rank j (the lanes that stay push to the lanes behind, so
+    // the push is a permutation of all 64); place j then pulls from there, every other lane from itself
+    const unsigned stay = lane - __builtin_amdgcn_mbcnt_hi((unsigned)(Mv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Mv, 0u));
+    const int by_rank = __builtin_amdgcn_ds_permute((int)((moving ? rank : n_moving + stay) << 2), (int)lane);
+    const int from = __builtin_amdgcn_ds_bpermute((int)(place << 2), by_rank);
+    const int src = (moving ? from : (int)lane) << 2;
+#define HPT_MOVE_F(x) x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(x)))
+#define HPT_MOVE_I(x) x = (std::remove_reference_t<decltype(x)>)__builtin_amdgcn_ds_bpermute(src, (int)(x))
+    HPT_MOVE_F(r.o.x); HPT_MOVE_F(r.o.y); HPT_MOVE_F(r.o.z); HPT_MOVE_F(r.d.x); HPT_MOVE_F(r.d.y); HPT_MOVE_F(r.d.z);
+    HPT_MOVE_F(color.x); HPT_MOVE_F(color.y); HPT_MOVE_F(color.z); HPT_MOVE_F(weight.x); HPT_MOVE_F(weight.y); HPT_MOVE_F(weight.z);
+    HPT_MOVE_I(b); HPT_MOVE_I(out_idx); HPT_MOVE_I(key); HPT_MOVE_I(ctr);
+    // all sixteen have arrived before the step ends: a permute still in flight at the next TRI / NODE step makes hipcc
+    // put an s_waitcnt inside that step's group of loads (tests/test_host.py checks the groups)
+    asm volatile("" : : "v"(r.o.x), "v"(r.o.y), "v"(r.o.z), "v"(r.d.x), "v"(r.d.y), "v"(r.d.z), "v"(color.x), "v"(color.y));
+    asm volatile("" : : "v"(color.z), "v"(weight.x), "v"(weight.y), "v"(weight.z), "v"(b), "v"(out_idx), "v"(key), "v"(ctr));
+#undef HPT_MOVE_F
+#undef HPT_MOVE_I
 }
 
 // Persistent wavefront render kernel.
@@ -870,6 +929,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) HPT_SGPR_CAP render_kernel
         if (nS >= p.shade_threshold || nN + nT == 0) {
             {
                 Ray r;
+                r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 1);
                 int gid = -1, s = 0;     // pixel and iteration of a path fetched in this step (only its key and camera ray need them)
                 bool ended = false;
                 n_primary += (unsigned)__popcll(hpt_ballot(wantS && b == 0));
@@ -929,8 +989,11 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) HPT_SGPR_CAP render_kernel
                         color = mk3(0, 0, 0); weight = mk3(1, 1, 1);
                         b = 0;
                     }
-                    trav_start<LONG>(p, tv, r.o, r.d);
                 }
+                // The paths that start a ray in this step change lanes before they start it (regroup_starting()):
+                // not for long primitive lists, whose SHADE step is what the wave spends its time in
+                if (!LONG) regroup_starting(wantS && tv.cur != HPT_REF_IDLE, lane, r, b, out_idx, key, ctr, color, weight);
+                if (wantS && tv.cur != HPT_REF_IDLE) trav_start<LONG>(p, tv, r.o, r.d);
             }
         } else if (nT > nN) {
             trav_tri_steps<SINGLES, COUNT>(p, tv, stack, stride, spill, nT, n_loads);
