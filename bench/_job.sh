@@ -1,6 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out/r02p
-bash bench/steps.sh gpurun_out/r02p \
- "300 ab python bench/ab.py --spp 32 --rounds 3 new=pathtracer_amd/libhpt.so narrow=build/libhpt_narrow.so" \
- "300 ab_c2 python bench/ab.py --scene bunny --spp 64 --rounds 2 new=pathtracer_amd/libhpt.so narrow=build/libhpt_narrow.so"
-grep -h "^{" gpurun_out/r02p/ab*.log
+mkdir -p gpurun_out/r02q
+bash bench/steps.sh gpurun_out/r02q \
+ "200 prof HPT_LIB=build/libhpt_prof.so python bench/step_profile.py sponza 2" \
+ "200 prof_c4 HPT_LIB=build/libhpt_prof.so python bench/step_profile.py tenm 1"

@@ -1003,7 +1003,8 @@ int hpt_get_stats(hpt_ctx *ctx, hpt_stats *stats) {
             c[3] / 64, c[4] / 64, c[5] / 64, c[6], c[7], c[8], c[3] ? (double)c[6] / c[3] : 0.0, c[4] ? (double)c[7] / c[4] : 0.0,
             c[5] ? (double)c[8] / c[5] : 0.0);
     fprintf(stderr, "[hpt profile] NODE iterations %llu (%.1f lanes each), all lanes at one node: %.3f of iterations; distinct nodes per quad / lane-visits %.3f\n",
-            c[11], c[11] ? (double)c[13] / c[11] : 0.0, c[11] ? (double)c[12] / c[11] : 0.0, c[13] ? (double)c[14] / c[13] : 0.0);
+            c[11], c[11] ? (double)c[13] / c[11] : 0.0, c[11] ? (double)(c[12] & 0xfffffull) / c[11] : 0.0, c[13] ? (double)c[14] / c[13] : 0.0);
+    fprintf(stderr, "[hpt profile] distinct nodes per WAVE / lane-visits %.3f\n", c[13] ? (double)(c[12] >> 20) / c[13] : 0.0);
     fprintf(stderr, "[hpt profile] of all lane-trips: waiting for SHADE %.3f, out of work %.3f\n",
             (double)c[9] / (double)(c[3] + c[4] + c[5]), (double)c[10] / (double)(c[3] + c[4] + c[5]));
 #endif

@@ -745,10 +745,19 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
             const int c2 = __builtin_amdgcn_mov_dpp(mine, 0xaa, 0xf, 0xf, true);
             const bool leader = in && !(qk > 0u && c0 == mine) && !(qk > 1u && c1 == mine) && !(qk > 2u && c2 == mine);
             const unsigned long long Lq = hpt_ballot(leader);
+            // lanes that are the first of the WAVE at their node: what any re-ordering inside the wave could reach
+            bool first_in_wave = in;
+            for (unsigned long long mm = act; mm != 0ull; mm &= mm - 1ull) {
+                const int j = __builtin_ctzll(mm);
+                const int cj = __builtin_amdgcn_readlane(s.cur, j);
+                if ((unsigned)j < (threadIdx.x & 63u) && cj == s.cur) first_in_wave = false;
+            }
+            const unsigned long long Lw = hpt_ballot(first_in_wave);
             if (act != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(act)) {
                 atomicAdd(p.counters + 11, 1ull); atomicAdd(p.counters + 13, (unsigned long long)__popcll(act));
                 if (U != 0ull) atomicAdd(p.counters + 12, 1ull);
                 atomicAdd(p.counters + 14, (unsigned long long)__popcll(Lq));
+                atomicAdd(p.counters + 12, (unsigned long long)__popcll(Lw) << 20);
             }
         }
 #endif
