@@ -1,5 +1,7 @@
 set -o pipefail
-mkdir -p gpurun_out/r02q
-bash bench/steps.sh gpurun_out/r02q \
- "200 prof HPT_LIB=build/libhpt_prof.so python bench/step_profile.py sponza 2" \
- "200 prof_c4 HPT_LIB=build/libhpt_prof.so python bench/step_profile.py tenm 1"
+mkdir -p gpurun_out/r02z
+timeout -k 10 600 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r02z/gpu_tests.log 2>&1
+rc=$?; tail -n 3 gpurun_out/r02z/gpu_tests.log
+case $rc in 0) ;; *) echo "tests rc=$rc"; exit $rc;; esac
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+bash bench/profile_all.sh r02z
