@@ -1,7 +1,7 @@
 set -o pipefail
-mkdir -p gpurun_out/r02z
-timeout -k 10 600 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r02z/gpu_tests.log 2>&1
-rc=$?; tail -n 3 gpurun_out/r02z/gpu_tests.log
-case $rc in 0) ;; *) echo "tests rc=$rc"; exit $rc;; esac
-cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-bash bench/profile_all.sh r02z
+mkdir -p gpurun_out/r02r
+bash bench/steps.sh gpurun_out/r02r \
+ "300 ab python bench/ab.py --spp 32 --rounds 2 new=pathtracer_amd/libhpt.so nt=build/libhpt_nt.so" \
+ "300 ab_c4 python bench/ab.py --scene tenm --spp 4 --rounds 2 new=pathtracer_amd/libhpt.so nt=build/libhpt_nt.so" \
+ "300 ab_c2 python bench/ab.py --scene bunny --spp 64 --rounds 2 new=pathtracer_amd/libhpt.so nt=build/libhpt_nt.so"
+grep -h "^{" gpurun_out/r02r/ab*.log
