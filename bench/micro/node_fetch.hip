@@ -3,6 +3,7 @@
 //   0  today's NODE step: every active lane issues four global_load_dwordx4 of its own node
 //   1  quad-cooperative: load k (k = 0..3) fetches the node of quad-lane k with the quad's four lanes (one 64-B line
 //      per quad), straight into LDS (global_load_lds_dwordx4); the owner reads its 64 B back with 4 ds_read_b128
+//   4  in-register pairing (<= 32 active lanes): owner + idle helper fetch half a node each in two loads, 8 ds_bpermute
 //   2  compacted: the active lanes' node indices are compacted through LDS, ceil(n/16) loads fetch 16 nodes each
 //      (4 lanes per node) into LDS, the owner (rank r) reads node r back
 // Node indices: 84 % from a 16-KB hot set, the rest uniform over the table (C3's measured L1 hit rate).
@@ -54,6 +55,40 @@ __global__ __launch_bounds__(256) void emu(const float4 *__restrict__ tab, unsig
                 acc += sum16(n[0], n[1], n[2], n[3]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (V == 4) {
+            // in-register pairing: with at most 32 lanes in the NODE state every active lane gets an idle lane as a helper;
+            // owner and helper fetch one half of the node each in TWO load instructions (instead of four), the owner
+            // pulls the helper's half over with 8 ds_bpermute.  More than 32 active lanes: today's four loads.
+            unsigned long long in = __ballot(on);
+            unsigned n_in = __popcll(in);
+            if (n_in > 32u) {
+                if (on) {
+                    const float4 *n = tab + (size_t)node * 4;
+                    acc += sum16(n[0], n[1], n[2], n[3]);
+                }
+            } else {
+                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(in >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)in, 0u));
+                const unsigned rank = below, irank = lane - below;               // among the active / among the idle lanes
+                const int by_pos = __builtin_amdgcn_ds_permute((int)((on ? rank : n_in + irank) << 2), (int)lane);
+                const int partner = __builtin_amdgcn_ds_bpermute((int)((on ? n_in + rank : irank) << 2), by_pos);
+                const unsigned pnode = (unsigned)__builtin_amdgcn_ds_bpermute(partner << 2, (int)node);
+                const bool helps = !on && irank < n_in;
+                float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+                if (on || helps) {
+                    const float4 *n = tab + (size_t)(on ? node : pnode) * 4 + (on ? 0 : 2);
+                    r0 = n[0]; r1 = n[1];
+                }
+                float4 z, m;
+                z.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r0.x)));
+                z.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r0.y)));
+                z.z = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r0.z)));
+                z.w = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r0.w)));
+                m.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r1.x)));
+                m.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r1.y)));
+                m.z = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r1.z)));
+                m.w = __int_as_float(__builtin_amdgcn_ds_bpermute(partner << 2, __float_as_int(r1.w)));
+                if (on) acc += sum16(r0, r1, z, m);
+            }
         } else if (V == 3) {
             // variant 2 with the pieces of node c' rotated by c'>>2 inside its 64 B of LDS: 16 consecutive ranks then
             // read 16 different 16-B bank groups in every one of the four ds_read_b128
@@ -115,7 +150,7 @@ int main(int argc, char **argv) {
     const double ps[5] = {0.2, 0.38, 0.5, 0.75, 1.0};
     for (int pi = 0; pi < 5; pi++) {
         unsigned thr = (unsigned)(ps[pi] * 65536.0);
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < 5; v++) {
             float ms = 0;
             for (int rep = 0; rep < 2; rep++) {
                 int it = rep ? iters : 10;
@@ -123,7 +158,8 @@ int main(int argc, char **argv) {
                 if (v == 0) emu<0><<<blocks, threads, 4 * kWaveLds>>>(tab, n_nodes, thr, it, out);
                 else if (v == 1) emu<1><<<blocks, threads, 4 * kWaveLds>>>(tab, n_nodes, thr, it, out);
                 else if (v == 2) emu<2><<<blocks, threads, 4 * kWaveLds>>>(tab, n_nodes, thr, it, out);
-                else emu<3><<<blocks, threads, 4 * kWaveLds>>>(tab, n_nodes, thr, it, out);
+                else if (v == 3) emu<3><<<blocks, threads, 4 * kWaveLds>>>(tab, n_nodes, thr, it, out);
+                else emu<4><<<blocks, threads, 4 * kWaveLds>>>(tab, n_nodes, thr, it, out);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&ms, e0, e1));
             }
