@@ -16,7 +16,7 @@ import json, os, sys, time
 sys.path.insert(0, %(root)r)
 import torch
 from pathtracer_amd import api, scenes
-scn = scenes.scene(%(scene)r)
+scn = scenes.scene(%(scene)r, **%(kw)r)
 bvh = api.build_bvh(scn["verts"])
 be = api.Backend(scn["width"], scn["height"])
 be.load(scn, bvh)
@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--kw", default="", help="scene keywords, e.g. copies=1000")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     res = {}
@@ -49,7 +50,8 @@ def main():
             for kv in parts[1:]:
                 k, val = kv.split("=")
                 env[k] = val
-            code = CHILD % dict(root=ROOT, scene=a.scene, reps=a.reps, spp=a.spp)
+            code = CHILD % dict(root=ROOT, scene=a.scene, reps=a.reps, spp=a.spp,
+                                kw={k: int(v) for k, v in (kv.split("=") for kv in a.kw.split(",") if kv)})
             out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(name, "FAILED", out.stderr[-500:], flush=True)
