@@ -128,6 +128,7 @@ struct hpt_ctx {
     bool shade_threshold_fixed = false;
     int tris_per_trip = 8;
     int node_repeat_min = 24;
+    int tri_weight = 8;              // HPT_TRI_WEIGHT: a lane in the TRI state counts tri_weight / 4 NODE lanes when the wave picks its step
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
     int tail_chunks = 4;             // the last tail_chunks x waves x fetch_chunk work items of a launch are reserved 64 at a time (HPT_TAIL_CHUNKS; 2/4/8/16: 701.8/700.7/700.5/700.6 ms at C3)
     int fetch_threshold = 32;        // iter_trace_kernel's FETCH step threshold (HPT_FETCH_THRESHOLD overrides)
@@ -296,6 +297,7 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
                                                    : ctx->shade_threshold + (ctx->n_prims / 8 < 16 ? ctx->n_prims / 8 : 16);
     p.tris_per_trip = ctx->tris_per_trip;
     p.node_repeat_min = ctx->node_repeat_min;
+    p.tri_weight = ctx->tri_weight;
     p.fetch_chunk = ctx->fetch_chunk;
     p.fetch_threshold = ctx->fetch_threshold;
     return HPT_OK;
@@ -507,6 +509,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_LEAF_RECORDS")) ctx->leaf_records = !strcmp(e, "singles") ? 1 : !strcmp(e, "pairs") ? 2 : 0;
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
+    if (const char *e = getenv("HPT_TRI_WEIGHT")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->tri_weight = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
     if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->fetch_chunk = v; }
     if (const char *e = getenv("HPT_TAIL_CHUNKS")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->tail_chunks = v; }

@@ -63,6 +63,7 @@ struct RenderParams {
     int32_t shade_threshold;         // lanes that must want SHADE before the wave runs it (scheduling only)
     int32_t tris_per_trip;           // triangles a TRI step may test before the wave re-votes (scheduling only)
     int32_t node_repeat_min;         // a NODE step repeats while this many lanes still want it (scheduling only; > 64 = never)
+    int32_t tri_weight;              // step choice: TRI when nT * tri_weight > nN * 4 (scheduling only; 8 = a TRI lane counts double)
     int32_t stack_cap;               // traversal-stack entries kept in LDS per lane; deeper entries go to `spill`
     uint2 *spill;                    // [entry - stack_cap][grid lane], HBM; only touched by rays deeper than stack_cap
     uint32_t spill_stride;           // lanes in the grid
@@ -927,7 +928,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) HPT_SGPR_CAP render_kernel
         if (nS + nN + nT == 0) break;
 #ifdef HPT_PROFILE_STEPS
         {   // development build: per-kind trips and active lanes (bench/ab.py prints them)
-            int kind = (nS >= p.shade_threshold || nN + nT == 0) ? 0 : ((nT > nN) ? 1 : 2);
+            int kind = (nS >= p.shade_threshold || nN + nT == 0) ? 0 : ((nT * p.tri_weight > nN * 4) ? 1 : 2);
             prof_it[kind]++;
             if ((kind == 0 && wantS) || (kind == 1 && wantT) || (kind == 2 && wantN)) prof_act[kind]++;
             if (kind != 0 && wantS) prof_waitS++;
@@ -1004,7 +1005,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) HPT_SGPR_CAP render_kernel
                 if (!LONG) regroup_starting(wantS && tv.cur != HPT_REF_IDLE, lane, r, b, out_idx, key, ctr, color, weight);
                 if (wantS && tv.cur != HPT_REF_IDLE) trav_start<LONG>(p, tv, r.o, r.d);
             }
-        } else if (nT > nN) {
+        } else if (nT * p.tri_weight > nN * 4) {     // a lane in the TRI state counts tri_weight / 4 lanes in the NODE state
             trav_tri_steps<SINGLES, COUNT>(p, tv, stack, stride, spill, nT, n_loads);
         } else {
             trav_node_steps<COUNT>(p, tv, stack, stride, spill, nN, n_loads);
@@ -1141,7 +1142,7 @@ __global__ void __launch_bounds__(256, HPT_MIN_WAVES) iter_trace_kernel(const Re
                 traced++;
                 trav_start<LONG>(p, tv, o, d);
             }
-        } else if (nT > nN) {
+        } else if (nT * p.tri_weight > nN * 4) {
             trav_tri_steps<SINGLES, false>(p, tv, stack, stride, spill, nT, n_loads);
         } else {
             trav_node_steps<false>(p, tv, stack, stride, spill, nN, n_loads);
