@@ -95,6 +95,7 @@ struct hpt_ctx {
     float4 *d_pairs = nullptr;
     bool pairs_dirty = true;
     bool singles = false;            // record form of the current tree: one triangle per 48-B record (ensure_pairs)
+    size_t tree_bytes = 0;           // nodes + triangle records of the current tree as the traversal reads them (ensure_pairs)
     int leaf_records = 0;            // HPT_LEAF_RECORDS: 0 = per tree, 1 = singles, 2 = pairs
     hpt_primitive *d_prims = nullptr;
     PrimCompact *d_prim_compact = nullptr;   // centre, radius, type, plane normal of each primitive (render_kernels.h)
@@ -256,6 +257,7 @@ int ensure_pairs(hpt_ctx *ctx) {
     if ((rc = replace_buffer(ctx, ctx->d_pairs, rec.data(), rec.size() * sizeof(float)))) return rc;
     ctx->root_ref = root;
     ctx->singles = singles;
+    ctx->tree_bytes = wide.size() * sizeof(WideNode) + rec.size() * sizeof(float);
     ctx->pairs_dirty = false;
     return HPT_OK;
 }
@@ -311,6 +313,7 @@ size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
 // Dynamic LDS any kernel here may ask for: a full-depth stack (kMaxTreeDepth entries of 8 B for 256 lanes).  Set once
 // per kernel (the attribute is per function, so every context sets the same value), with the occupancy at the
 // launch's actual LDS size cached beside it: neither is asked of the runtime again on later launches.
+constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
 constexpr size_t kMaxDynamicLds = (size_t)kMaxTreeDepth * kBlock * sizeof(uint2);
 
 int kernel_shape(hpt_ctx *ctx, const void *kernel, size_t lds, int &blocks_per_cu) {
@@ -454,6 +457,9 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
             p.batch = (l_end - base) < batch ? (l_end - base) : batch;
             p.n_work = p.n_slots * (uint32_t)p.batch;
             long blocks = blocks_max;
+            // a tree that does not fit the 256-MB Infinity Cache streams from HBM, and a seventh block per CU only adds
+            // misses in flight (C4 166 -> 171 ms; 378 MB -1.1 %, 126 MB +0.9 %): six blocks per CU for those
+            if (ctx->tree_bytes > kStreamingTreeBytes && blocks > 6L * ctx->n_cu) blocks = 6L * ctx->n_cu;
             // a launch of fewer than four paths per lane is mostly ramp and drain: one block per CU fewer then
             // (C1's 1 M paths: 0.737 -> 0.708 ms at 6 instead of 7 blocks per CU; from ~8 paths per lane the full grid wins)
             if (blocks >= 7L * ctx->n_cu && (long)p.n_work < 4L * blocks * kBlock) blocks -= ctx->n_cu;

@@ -888,16 +888,20 @@ __device__ __forceinline__ void regroup_starting(bool moving, unsigned lane, Ray
 // form at 12 % lane utilisation (profiles/r01_v1_naive).  SHADE is the expensive, rare step, so it waits
 // until p.shade_threshold lanes want it or nothing else is runnable.  Work order per path is unchanged,
 // so results stay bit-identical to the oracle.
-// Waves per SIMD.  Pair-record trees (C1, C3, C5): 7 (72 VGPRs, 94 SGPRs -- the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16))
-// blocks of 256 per CU -- and 8-20 B of scratch per lane): +1.7 % at C3 and +5.6 % at C5 over 6 since the re-grouping and the
-// step weights took load off the L1 (before them 7 lost 0.7 %).  Single-record trees: 6 (80 VGPRs, no scratch): C4, whose tree
-// streams from HBM, loses 3.3 % at 7.  iter_trace_kernel: 6 (7 costs 1.7 % per call).  8 spills 52 B per lane and gains
-// nothing (profiles/r02_tuning.md).
+// Waves per SIMD of render_kernel: 7 (72 VGPRs, 94 SGPRs -- the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16)) blocks of
+// 256 per CU -- and 8-20 B of scratch per lane, loop-invariant values re-read only in SHADE): +1.7 % at C3, +1.5 % at C2 and
+// +5.6 % at C5 over 6 since the re-grouping and the step weights took load off the L1 (before them 7 lost 0.7 %).  Trees that
+// stream from HBM lose with the seventh block (C4 -3.3 %, 378 MB -1.1 %, 126 MB +0.9 %): the host launches six blocks per
+// CU of the same kernel for them (launch_render(), as fast as a 6-wave build).  iter_trace_kernel: 6 (HPT_MIN_WAVES; 7 costs
+// 1.7 % per call).  8 spills 52 B per lane and gains nothing at C3 (profiles/r02_tuning.md).
 #ifndef HPT_MIN_WAVES
 #define HPT_MIN_WAVES 6
 #endif
 #ifndef HPT_MIN_WAVES_PAIRS
 #define HPT_MIN_WAVES_PAIRS 7
+#endif
+#ifndef HPT_MIN_WAVES_LONG           // pair-record trees with a long primitive list (C5): 8 (64 VGPRs, 56 B of scratch per lane; the eight
+#define HPT_MIN_WAVES_LONG 8         // 20-KB LDS stacks fill the CU's 160 KB exactly): +2.0 % over 7, its SHADE steps leave the L1 idle
 #endif
 #ifdef HPT_MAX_SGPRS                 // development: cap the SGPRs (the hardware admits floor(800 / (ceil(sgpr/16)*16 + 16)) blocks of 256 per CU)
 #define HPT_SGPR_CAP __attribute__((amdgpu_num_sgpr(HPT_MAX_SGPRS)))
@@ -905,7 +909,7 @@ __device__ __forceinline__ void regroup_starting(bool moving, unsigned lane, Ray
 #define HPT_SGPR_CAP
 #endif
 template <bool SINGLES, bool COUNT, bool LONG>
-__global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES : HPT_MIN_WAVES_PAIRS)) HPT_SGPR_CAP render_kernel(const RenderParams p) {
+__global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? HPT_MIN_WAVES_LONG : HPT_MIN_WAVES_PAIRS)) HPT_SGPR_CAP render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
     unsigned n_primary = 0, n_bounce = 0, n_paths = 0;   // per WAVE (from ballots: scalar registers, not three per lane)
