@@ -830,7 +830,8 @@ __device__ __forceinline__ void trav_start(const RenderParams &p, Trav &s, f3 o,
 // (same octant = same near/far child at every node), and the places are taken quads with four moving lanes first,
 // then three, ..., so that runs of one octant fill whole quads.  Which lane computes a path does not enter its
 // result (the RNG is keyed by path, the sample slot travels with it), so images stay bit-identical.
-// C3: distinct nodes per quad / lane-visits 0.928 -> 0.827, 88.4 -> 86.3 ms at 32 spp (profiles/r02_tuning.md).
+// C3: distinct nodes per quad / lane-visits 0.928 -> 0.827, 88.4 -> 86.3 ms at 32 spp; C5 +1.4 % once it ran 8 waves per SIMD
+// (at 6 it lost 0.5 %) (profiles/r02_tuning.md).
 __device__ __forceinline__ void regroup_starting(bool moving, unsigned lane, Ray &r, int &b, unsigned &out_idx,
                                                  uint32_t &key, uint32_t &ctr, f3 &color, f3 &weight) {
     const unsigned long long Mv = hpt_ballot(moving);
@@ -1011,9 +1012,8 @@ __global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? H
                         b = 0;
                     }
                 }
-                // The paths that start a ray in this step change lanes before they start it (regroup_starting()):
-                // not for long primitive lists, whose SHADE step is what the wave spends its time in
-                if (!LONG) regroup_starting(wantS && tv.cur != HPT_REF_IDLE, lane, r, b, out_idx, key, ctr, color, weight);
+                // The paths that start a ray in this step change lanes before they start it (regroup_starting())
+                regroup_starting(wantS && tv.cur != HPT_REF_IDLE, lane, r, b, out_idx, key, ctr, color, weight);
                 if (wantS && tv.cur != HPT_REF_IDLE) trav_start<LONG>(p, tv, r.o, r.d);
             }
         } else if (nT * p.tri_weight > nN * 4) {     // a lane in the TRI state counts tri_weight / 4 lanes in the NODE state
