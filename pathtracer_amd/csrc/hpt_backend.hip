@@ -129,6 +129,7 @@ struct hpt_ctx {
     bool shade_threshold_fixed = false;
     int tris_per_trip = 8;
     int node_repeat_min = 24;
+    int pair_fetch = -1;             // HPT_PAIR_FETCH=0/1 forces the helper-lane node fetch off / on (default: single-record trees of 1 GB and more)
     int tri_weight = 8;              // HPT_TRI_WEIGHT: a lane in the TRI state counts tri_weight / 4 NODE lanes when the wave picks its step
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
     int tail_chunks = 4;             // the last tail_chunks x waves x fetch_chunk work items of a launch are reserved 64 at a time (HPT_TAIL_CHUNKS; 2/4/8/16: 701.8/700.7/700.5/700.6 ms at C3)
@@ -262,6 +263,9 @@ int ensure_pairs(hpt_ctx *ctx) {
     return HPT_OK;
 }
 
+constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
+constexpr size_t kPairFetchTreeBytes = (size_t)1 << 30;       // helper-lane node fetch: measured to pay at 1.26 GB, to cost 1-3 % at 378 MB
+
 int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, int spp_end, int raw) {
     if (!ctx->have_camera) return fail(ctx, HPT_ERR_INVALID, "hpt_set_camera has not been called");
     if (ctx->root_ref != HPT_REF_DONE && ctx->max_leaf_end > ctx->n_tris)
@@ -313,7 +317,6 @@ size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
 // Dynamic LDS any kernel here may ask for: a full-depth stack (kMaxTreeDepth entries of 8 B for 256 lanes).  Set once
 // per kernel (the attribute is per function, so every context sets the same value), with the occupancy at the
 // launch's actual LDS size cached beside it: neither is asked of the runtime again on later launches.
-constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
 constexpr size_t kMaxDynamicLds = (size_t)kMaxTreeDepth * kBlock * sizeof(uint2);
 
 int kernel_shape(hpt_ctx *ctx, const void *kernel, size_t lds, int &blocks_per_cu) {
@@ -414,7 +417,13 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
     static const render_fn kRender[2][2][2] = {
         {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
         {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
-    const render_fn fn = kRender[ctx->singles ? 1 : 0][ctx->count_loads ? 1 : 0][ctx->n_prims >= HPT_TWO_PHASE_MIN_PRIMS ? 1 : 0];
+    // single-record trees of a gigabyte and more (short primitive lists): the instantiation whose NODE step fetches with helper lanes
+    static const render_fn kRenderPair[2] = {render_kernel<true, false, false, true>, render_kernel<true, true, false, true>};
+    const bool long_list = ctx->n_prims >= HPT_TWO_PHASE_MIN_PRIMS;
+    const bool pair_fetch = ctx->singles && !long_list &&
+                            (ctx->pair_fetch >= 0 ? ctx->pair_fetch != 0 : ctx->tree_bytes >= kPairFetchTreeBytes);
+    const render_fn fn = pair_fetch ? kRenderPair[ctx->count_loads ? 1 : 0]
+                                    : kRender[ctx->singles ? 1 : 0][ctx->count_loads ? 1 : 0][long_list ? 1 : 0];
     if ((rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max, noalloc, &scratch_used))) return rc;
 
     // paths (= 12-B samples) per launch: the sample buffer, and 32-bit work indices with headroom for the work
@@ -518,6 +527,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_TRIS_PER_TRIP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->tris_per_trip = v; }
     if (const char *e = getenv("HPT_LEAF_RECORDS")) ctx->leaf_records = !strcmp(e, "singles") ? 1 : !strcmp(e, "pairs") ? 2 : 0;
     if (const char *e = getenv("HPT_NODE_REPEAT_MIN")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->node_repeat_min = v; }
+    if (const char *e = getenv("HPT_PAIR_FETCH")) ctx->pair_fetch = atoi(e) != 0;
     if (const char *e = getenv("HPT_TRI_WEIGHT")) { int v = atoi(e); if (v >= 1 && v <= 256) ctx->tri_weight = v; }
     if (const char *e = getenv("HPT_SAMPLE_BUDGET_MB")) { long v = atol(e); if (v >= 1) ctx->sample_budget_bytes = (size_t)v << 20; }
     if (const char *e = getenv("HPT_FETCH_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 4096) ctx->fetch_chunk = v; }

@@ -726,10 +726,16 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
 
 // NODE step: both children per visit; the wave stays here, without a full re-vote, while at least
 // node_repeat_min lanes still have an interior node to test.
-template <bool COUNT>
+// PAIR (an instantiation of render_kernel of its own, picked by the host for single-record trees of a gigabyte and more,
+// whose every node fetch is a miss to HBM): while at most 32 lanes are at a node, each of them takes an idle lane as helper (one
+// ds_permute + two ds_bpermute to find each other and pass the node index); owner and helper fetch half the node each, in
+// TWO load instructions instead of four, and the owner pulls the other half over with seven ds_bpermute.  Same 4 lane-loads
+// per visit.  C4 +2.2 %; smaller trees lose 3-7 % to the three extra hops in front of every fetch (profiles/r02_tuning.md).
+template <bool COUNT, bool PAIR = false>
 __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill,
                                                 int n_in, unsigned long long &loads) {
     if (COUNT) loads += (unsigned)(n_in * 4);
+    int n_now = n_in;
     for (;;) {
 #ifdef HPT_PROFILE_STEPS
         {   // development build: how many NODE iterations have all their lanes at ONE node (a scalar load would do)
@@ -762,13 +768,46 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
             }
         }
 #endif
+        const bool pair_mode = PAIR && n_now <= 32;        // wave-uniform
+        float4 pA = make_float4(0, 0, 0, 0), pB = pA, pZ = pA; int4 pM = make_int4(0, 0, 0, 0);
+        if (PAIR && pair_mode) {
+            const unsigned lane = threadIdx.x & 63u;
+            const bool in = (unsigned)s.cur < (unsigned)HPT_REF_IDLE;
+            const unsigned long long IN = hpt_ballot(in);
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(IN >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)IN, 0u));
+            const unsigned irank = lane - below, n_act = (unsigned)__popcll(IN);
+            const int by_pos = __builtin_amdgcn_ds_permute((int)((in ? below : n_act + irank) << 2), (int)lane);
+            const int partner = __builtin_amdgcn_ds_bpermute((int)((in ? n_act + below : irank) << 2), by_pos) << 2;
+            const int pcur = __builtin_amdgcn_ds_bpermute(partner, s.cur);
+            const bool helps = !in && irank < n_act;
+            if (in || helps) {
+                const unsigned off = ((unsigned)(in ? s.cur : pcur) << 6) + (in ? 0u : 32u);
+                const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + off);
+                pA = q[0]; pB = q[1];
+                HPT_KEEP_ADDRESS(off, pB.w);
+            }
+            pZ.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(pA.x)));
+            pZ.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(pA.y)));
+            pZ.z = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(pA.z)));
+            pZ.w = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(pA.w)));
+            pM.x = __builtin_amdgcn_ds_bpermute(partner, __float_as_int(pB.x));
+            pM.y = __builtin_amdgcn_ds_bpermute(partner, __float_as_int(pB.y));
+            pM.z = __builtin_amdgcn_ds_bpermute(partner, __float_as_int(pB.z));
+            // landed before the step goes on (a permute in flight at the next TRI step would put an s_waitcnt into its load group)
+            asm volatile("" : : "v"(pZ.x), "v"(pZ.y), "v"(pZ.z), "v"(pZ.w), "v"(pM.x), "v"(pM.y), "v"(pM.z));
+        }
         if ((unsigned)s.cur < (unsigned)HPT_REF_IDLE) {
             // 32-bit byte offset (n_wide < 2^25): saddr + voffset addressing, no 64-bit address math
-            const unsigned node_off = (unsigned)s.cur << 6;
-            const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + node_off);
-            const float4 X = q[0], Y = q[1], Z = q[2];
-            const int4 m = *reinterpret_cast<const int4 *>(q + 3);
-            HPT_KEEP_ADDRESS(node_off, m.w);
+            float4 X, Y, Z; int4 m;
+            if (PAIR && pair_mode) {
+                X = pA; Y = pB; Z = pZ; m = pM;
+            } else {
+                const unsigned node_off = (unsigned)s.cur << 6;
+                const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + node_off);
+                X = q[0]; Y = q[1]; Z = q[2];
+                m = *reinterpret_cast<const int4 *>(q + 3);
+                HPT_KEEP_ADDRESS(node_off, m.w);
+            }
             const bool nx = s.flags & 1u, ny = s.flags & 2u, nz = s.flags & 4u;
             float t0, t1;
             unsigned long long M0, M1;                    // lanes whose child 0 / child 1 is hit with tmin < t
@@ -789,6 +828,7 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
         }
         const int again = __popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE));
         if (again < p.node_repeat_min) break;
+        n_now = again;
         if (COUNT) loads += (unsigned)(again * 4);
     }
 }
@@ -909,7 +949,7 @@ __device__ __forceinline__ void regroup_starting(bool moving, unsigned lane, Ray
 #else
 #define HPT_SGPR_CAP
 #endif
-template <bool SINGLES, bool COUNT, bool LONG>
+template <bool SINGLES, bool COUNT, bool LONG, bool PAIR = false>
 __global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? HPT_MIN_WAVES_LONG : HPT_MIN_WAVES_PAIRS)) HPT_SGPR_CAP render_kernel(const RenderParams p) {
     uint2 *stack = hpt_lds_stack + threadIdx.x;
     const int stride = blockDim.x;
@@ -1019,7 +1059,7 @@ __global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? H
         } else if (nT * p.tri_weight > nN * 4) {     // a lane in the TRI state counts tri_weight / 4 lanes in the NODE state
             trav_tri_steps<SINGLES, COUNT>(p, tv, stack, stride, spill, nT, n_loads);
         } else {
-            trav_node_steps<COUNT>(p, tv, stack, stride, spill, nN, n_loads);
+            trav_node_steps<COUNT, PAIR>(p, tv, stack, stride, spill, nN, n_loads);
         }
     }
     if (lane == 0u) {

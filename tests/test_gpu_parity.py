@@ -200,7 +200,9 @@ def test_config_diffuse_scale_depth_and_rr():
 @pytest.mark.parametrize("env", [dict(HPT_STACK_CAP="1"), dict(HPT_STACK_CAP="3", HPT_SHADE_THRESHOLD="1"),
                                  dict(HPT_SHADE_THRESHOLD="64", HPT_TRIS_PER_TRIP="1", HPT_NODE_REPEAT_MIN="65"),
                                  dict(HPT_TRIS_PER_TRIP="64", HPT_NODE_REPEAT_MIN="1", HPT_BLOCKS_PER_CU="1"),
-                                 dict(HPT_TRI_WEIGHT="1"), dict(HPT_TRI_WEIGHT="256", HPT_SHADE_THRESHOLD="7")])
+                                 dict(HPT_TRI_WEIGHT="1"), dict(HPT_TRI_WEIGHT="256", HPT_SHADE_THRESHOLD="7"),
+                                 dict(HPT_PAIR_FETCH="1", HPT_LEAF_RECORDS="singles"),       # the helper-lane NODE fetch of gigabyte trees
+                                 dict(HPT_PAIR_FETCH="1", HPT_LEAF_RECORDS="singles", HPT_NODE_REPEAT_MIN="1", HPT_STACK_CAP="2")])
 def test_scheduling_knobs_do_not_change_results(env, monkeypatch):
     """The wave scheduler's knobs (which step kind runs, how long, how much of the traversal stack sits in
     LDS before it overflows to HBM) only reorder work between lanes: every image stays bit-exact.

@@ -308,7 +308,7 @@ def test_node_loads_form_one_uninterrupted_group():
         # the node fetch (4 loads) and the triangle-record fetch (5: a pair record, 3: a single record)
         assert 4 in sizes and (5 in sizes or 3 in sizes), "%s: load groups %s" % (kname, sizes)
         checked += 1
-    assert checked == 12                                  # render_kernel (plain / counting, short / long primitive lists) and iter_trace_kernel, both record forms
+    assert checked == 14                                  # render_kernel (plain / counting, short / long primitive lists; helper-lane fetch) and iter_trace_kernel, both record forms
 
 
 def test_no_gpu_means_loud_failure():
