@@ -1,5 +1,5 @@
-// Test-only declaration of the reference's device-backend interface: the nine public methods of
-// class OpenCL_Manager (reference pathtracer/opencl_manager.hpp:13-50) with the argument types they name, so that
+// Test-only declaration of the reference's device-backend interface: the constructor and the nine public methods of
+// class OpenCL_Manager (reference pathtracer/opencl_manager.hpp:11-50) with the argument types they name, so that
 // the forwarding body printed in INTEGRATION.md can be compiled (tests/test_host.py::
 // test_integration_forwarding_body_compiles).  Boundary check only: it pins that the replacement body matches the
 // interface the reference's Pathtracer calls, nothing about parity.  The PODs are declared as far as the body
@@ -13,6 +13,7 @@ struct Triangle; struct BVH_Node_BBox; struct BVH_Node_Info; struct BVH_Node; st
 
 class OpenCL_Manager {
 public:
+    OpenCL_Manager();                       // opencl_manager.hpp:11, defined opencl_manager.cpp:42, called pathtracer.cpp:69
     int initialize(int width, int height);
     int kernel_load(std::string file_name, std::string kernel_name);
     int new_kernel_load(int kid, std::string file_name, std::string kernel_name);

@@ -344,7 +344,7 @@ def test_tile_exchange_index_math():
 
 def test_integration_forwarding_body_compiles(tmp_path):
     """The replacement body of OpenCL_Manager printed in INTEGRATION.md (what a reference maintainer would add)
-    compiles against a declaration of the reference's nine public methods (opencl_manager.hpp:13-50, restated in
+    compiles against a declaration of the reference's constructor and nine public methods (opencl_manager.hpp:11-50, restated in
     tests/native/ocl_decl/) and the C-ABI headers.  Boundary check only; it says nothing about parity."""
     import re
     import subprocess
@@ -360,4 +360,14 @@ def test_integration_forwarding_body_compiles(tmp_path):
     r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-c", str(src), "-o", str(tmp_path / "fwd.o"),
                         "-I" + os.path.join(ROOT, "tests", "native", "ocl_decl"), "-I" + os.path.join(ROOT, "include"),
                         "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # ... and LINKS with a caller that does what pathtracer.cpp:69-70 does (new OpenCL_Manager(); initialize(w, h)):
+    # a body without the constructor of opencl_manager.hpp:11 compiles but leaves this caller with an undefined symbol
+    assert "OpenCL_Manager::OpenCL_Manager()" in body
+    caller = tmp_path / "caller.cpp"
+    caller.write_text('#include "opencl_manager.hpp"\nint main() { OpenCL_Manager *m = new OpenCL_Manager(); return m->initialize(4, 4) ? 0 : 1; }\n')
+    r = subprocess.run(["g++", "-std=c++17", str(caller), str(tmp_path / "fwd.o"), "-o", str(tmp_path / "caller"),
+                        "-I" + os.path.join(ROOT, "tests", "native", "ocl_decl"), "-L" + os.path.join(ROOT, "pathtracer_amd"), "-lhpt",
+                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "pathtracer_amd"), "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
