@@ -26,26 +26,30 @@ EXTRA ?=
 OUT ?= build/libhpt_variant.so
 HOST_SRC = pathtracer_amd/csrc/host/bvh.cpp pathtracer_amd/csrc/host/obj_reader.cpp \
            pathtracer_amd/csrc/host/image_writer.cpp pathtracer_amd/csrc/host/pathtracer.cpp \
-           pathtracer_amd/csrc/host/host_capi.cpp
+           pathtracer_amd/csrc/host/host_capi.cpp pathtracer_amd/csrc/host/checkpoint.cpp
 HOST_OBJ = $(HOST_SRC:.cpp=.o)
 
 all: lib cli oracle scenes
 
 lib: pathtracer_amd/libhpt.so
 
-pathtracer_amd/csrc/host/%.o: pathtracer_amd/csrc/host/%.cpp $(wildcard pathtracer_amd/csrc/host/*.hpp) $(wildcard include/hpt/*.h)
+pathtracer_amd/csrc/host/%.o: pathtracer_amd/csrc/host/%.cpp $(wildcard pathtracer_amd/csrc/host/*.hpp) pathtracer_amd/csrc/hpt_internal.h $(wildcard include/hpt/*.h)
 	$(CXX) $(HOSTFLAGS) -c $< -o $@
 
 pathtracer_amd/csrc/hpt_backend.o: $(LIB_SRC) $(wildcard pathtracer_amd/csrc/*.h) $(wildcard include/hpt/*.h)
 	$(HIPCC) $(HIPFLAGS) -c $(LIB_SRC) -o $@
 
-pathtracer_amd/libhpt.so: pathtracer_amd/csrc/hpt_backend.o $(HOST_OBJ)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC pathtracer_amd/csrc/hpt_backend.o $(HOST_OBJ) -o $@
+# the multi-GPU exchange (RCCL through dlopen: no link-time dependency)
+pathtracer_amd/csrc/hpt_comm.o: pathtracer_amd/csrc/hpt_comm.hip pathtracer_amd/csrc/hpt_internal.h $(wildcard include/hpt/*.h)
+	$(HIPCC) $(HIPFLAGS) -c pathtracer_amd/csrc/hpt_comm.hip -o $@
 
-variant: $(HOST_OBJ)
+pathtracer_amd/libhpt.so: pathtracer_amd/csrc/hpt_backend.o pathtracer_amd/csrc/hpt_comm.o $(HOST_OBJ)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC pathtracer_amd/csrc/hpt_backend.o pathtracer_amd/csrc/hpt_comm.o $(HOST_OBJ) -ldl -o $@
+
+variant: $(HOST_OBJ) pathtracer_amd/csrc/hpt_comm.o
 	mkdir -p $(dir $(OUT))
 	$(HIPCC) $(HIPFLAGS) $(EXTRA) -c $(LIB_SRC) -o $(OUT).o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OUT).o $(HOST_OBJ) -o $(OUT)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $(OUT).o pathtracer_amd/csrc/hpt_comm.o $(HOST_OBJ) -ldl -o $(OUT)
 
 cli: pathtracer_amd/hpt_cli
 pathtracer_amd/hpt_cli: pathtracer_amd/csrc/host/hpt_cli.cpp pathtracer_amd/libhpt.so
@@ -67,6 +71,6 @@ build/%: bench/micro/%.hip
 	$(HIPCC) -O3 -std=c++17 --offload-arch=gfx950 $< -o $@
 
 clean:
-	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o
+	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o pathtracer_amd/csrc/hpt_comm.o
 
 .PHONY: all lib cli oracle scenes clean variant micro

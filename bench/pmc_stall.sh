@@ -1,6 +1,7 @@
 #!/bin/bash
 # Address-translation and TA/TCP stall counters of render_kernel (three rocprofv3 passes).
-# Usage: bash bench/pmc_stall.sh <tag> [bench.py args...]
+# Usage: bash bench/pmc_stall.sh <tag> [bench.py args...]      -> gpurun_out/pmc_<tag>/stall.txt (bench/pmc_stall_update.py folds it
+# into profiles/pmc_traffic.json)
 tag=$1; shift
 args=${@:---spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-count}
 out=gpurun_out/pmc_$tag
@@ -12,7 +13,7 @@ run() {
 run st1 TCP_UTCL1_REQUEST TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL GRBM_GUI_ACTIVE &&
 run st2 TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE &&
 run st3 TCP_UTCL1_STALL_MULTI_MISS TCP_UTCL1_STALL_INFLIGHT_MAX TCP_UTCL1_SERIALIZATION_STALL TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS GRBM_GUI_ACTIVE
-python - $out <<'P'
+python - $out <<'P' | tee $out/stall.txt
 import csv, sys, collections, os
 for name in ("st1", "st2", "st3"):
     path = f"{sys.argv[1]}/{name}_counter_collection.csv"

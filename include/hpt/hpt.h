@@ -175,6 +175,69 @@ int64_t hpt_slab_floats(const hpt_ctx *ctx);
 int hpt_pack_tiles(hpt_ctx *ctx, const float *d_image, float *d_slab);
 int hpt_unpack_tiles(hpt_ctx *ctx, const float *d_slabs, float *d_image);
 
+/* ---- Multi-GPU exchange inside the library (SURVEY.md §8b "multi-GPU handled inside the context", §8e) ----
+ * No counterpart in the reference: it drives platform 0 / GPU device 0 only (opencl_manager.cpp:57-73).  RCCL is
+ * called from C++ (librccl.so.1 is loaded on first use, so a one-GPU caller never needs it); the collectives are queued
+ * on the context's stream, in order with the render, without host synchronisation.
+ *
+ * One process (or host thread) per GPU: rank 0 calls hpt_comm_unique_id, hands the HPT_COMM_ID_BYTES bytes to the other
+ * ranks by any means (a file, MPI, a torch.distributed broadcast), and every rank calls hpt_comm_init with them; the
+ * call is collective (it returns when all `world` ranks have made it).  hpt_destroy releases the communicator.
+ *
+ * hpt_gather_tiles: tile shards (hpt_set_shard(rank, world) must equal the communicator's rank and size).  This
+ * rank's tiles of d_image -> slab, ONE ncclAllGather, every rank's slab -> d_image: afterwards every rank holds the
+ * whole frame, bit-identical to a one-GPU render (each pixel's samples are folded on one GPU in iteration order).
+ *
+ * hpt_reduce_samples: sample-range shards (hpt_set_sample_shard(rank, world) likewise).  d_image is this rank's
+ * running mean over its n_local samples; d_frame (may equal d_image when the rank's own mean is no longer needed)
+ * receives sum_r (n_r / n_total) * image_r through ONE ncclAllReduce: the frame's mean over n_total samples, within
+ * 1e-5 relative of the unsharded running mean (fp32 summation order).  A progressive render keeps d_image, calls
+ * hpt_render for the next slice of iterations and reduces into d_frame again ("reduce every K spp", BASELINE config 5). */
+#define HPT_COMM_ID_BYTES 128
+int hpt_comm_unique_id(void *id_out);
+int hpt_comm_init(hpt_ctx *ctx, const void *id, int rank, int world);
+int hpt_comm_destroy(hpt_ctx *ctx);
+int hpt_gather_tiles(hpt_ctx *ctx, float *d_image);
+int hpt_reduce_samples(hpt_ctx *ctx, const float *d_image, float *d_frame, int n_local, int n_total);
+
+/* One process, several GPUs: a group owns one context per device (each with a stream of its own, so the devices
+ * run side by side), one communicator over them (ncclCommInitAll) and one device image per member.  This is the form
+ * SURVEY.md §8b gives hpt_create (`n_devices`), kept apart so that hpt_create stays the one-device call the reference's
+ * initialize() maps onto.  The scene calls go to every member.  hpt_group_render = every member's hpt_render of its
+ * shard + the exchange, all asynchronous; afterwards every member's frame (hpt_group_frame) is the whole image.
+ * Sharding: HPT_SHARD_TILES (default; bit-identical to one GPU for any group size) or HPT_SHARD_SAMPLES (member r
+ * renders the iterations s % n == r; renders must then start at 0 or continue where the last one ended, and the frame
+ * is the reduced mean over all samples so far).  hpt_group_read_image copies member 0's frame to the host and waits;
+ * hpt_group_get_stats sums the members' ray counters and takes the longest of their times.  One host thread per group. */
+typedef struct hpt_group hpt_group;
+enum { HPT_SHARD_TILES = 0, HPT_SHARD_SAMPLES = 1 };
+int hpt_group_create(int width, int height, const int *devices, int n_devices, hpt_group **out);
+int hpt_group_destroy(hpt_group *g);
+const char *hpt_group_last_error(const hpt_group *g);      /* g == NULL: last hpt_group_create error */
+int hpt_group_size(const hpt_group *g);
+hpt_ctx *hpt_group_ctx(hpt_group *g, int member);
+float *hpt_group_frame(hpt_group *g, int member);          /* device pointer, width*height*3 floats */
+int hpt_group_set_sharding(hpt_group *g, int mode);
+int hpt_group_upload_triangles(hpt_group *g, const hpt_triangle *triangles, int n_triangles);
+int hpt_group_upload_bvh(hpt_group *g, const hpt_bvh_bbox *bbox, const hpt_bvh_info *info, int n_nodes);
+int hpt_group_set_scene(hpt_group *g, const hpt_primitive *primitives, int n_primitives,
+                        const hpt_material *materials, int n_materials);
+int hpt_group_set_camera(hpt_group *g, const hpt_camera *camera);
+int hpt_group_set_config(hpt_group *g, const hpt_config *cfg);
+int hpt_group_render(hpt_group *g, int spp_begin, int spp_end);
+int hpt_group_synchronize(hpt_group *g);
+int hpt_group_read_image(hpt_group *g, float *image_rgb);
+int hpt_group_get_stats(hpt_group *g, hpt_stats *stats);
+
+/* Checkpoint of a progressive render (the reference has only the 'p'-key PNG snapshot, main.cpp:194-203):
+ * the running-mean image, the number of iterations folded into it, the context's config and shards, and a checksum.
+ * hpt_checkpoint_save waits for the stream and writes `path` atomically (temporary file + rename);
+ * hpt_checkpoint_load refuses a file of another image size, config or shard (the continuation would be another
+ * render) or with a bad checksum, else fills d_image and *spp_done: hpt_render(ctx, *spp_done, n, d_image) then
+ * continues bit-identically to a render that was never interrupted. */
+int hpt_checkpoint_save(hpt_ctx *ctx, const float *d_image, int spp_done, const char *path);
+int hpt_checkpoint_load(hpt_ctx *ctx, float *d_image, int *spp_done, const char *path);
+
 /* 8-bit output of png_writer.cpp:7-17 / main.cpp:147-149:
  * (uint8)(255*clip(c,0,1)), truncation, no gamma. d_rgb8 = n_pixels*3 bytes. */
 int hpt_tonemap(hpt_ctx *ctx, const float *d_image, uint8_t *d_rgb8, int n_pixels);

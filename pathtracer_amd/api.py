@@ -24,7 +24,14 @@ C_ABI_SYMBOLS = [
     "hpt_unpack_tiles", "hpt_tonemap", "hpt_synchronize", "hpt_get_stats",
     "hpt_first_bounce", "hpt_bounce", "hpt_reconstruct_paths", "hpt_path_counts",
     "hpt_render_noalloc", "hpt_noalloc_scratch_bytes", "hpt_image_alloc", "hpt_image_free", "hpt_read_image",
+    "hpt_comm_unique_id", "hpt_comm_init", "hpt_comm_destroy", "hpt_gather_tiles", "hpt_reduce_samples",
+    "hpt_group_create", "hpt_group_destroy", "hpt_group_last_error", "hpt_group_size", "hpt_group_ctx", "hpt_group_frame",
+    "hpt_group_set_sharding", "hpt_group_upload_triangles", "hpt_group_upload_bvh", "hpt_group_set_scene", "hpt_group_set_camera",
+    "hpt_group_set_config", "hpt_group_render", "hpt_group_synchronize", "hpt_group_read_image", "hpt_group_get_stats",
+    "hpt_checkpoint_save", "hpt_checkpoint_load",
 ]
+COMM_ID_BYTES = 128
+SHARD_TILES, SHARD_SAMPLES = 0, 1
 
 
 class HptError(RuntimeError):
@@ -67,6 +74,30 @@ def lib():
             L.hpt_image_alloc.argtypes = [vp, C.POINTER(vp)]
             L.hpt_image_free.argtypes = [vp, vp]
             L.hpt_read_image.argtypes = [vp, vp, vp]
+        if not os.environ.get("HPT_LIB") or hasattr(L, "hpt_comm_init"):
+            L.hpt_comm_unique_id.argtypes = [vp]
+            L.hpt_comm_init.argtypes = [vp, vp, i32, i32]
+            L.hpt_comm_destroy.argtypes = [vp]
+            L.hpt_gather_tiles.argtypes = [vp, vp]
+            L.hpt_reduce_samples.argtypes = [vp, vp, vp, i32, i32]
+            L.hpt_group_create.argtypes = [i32, i32, C.POINTER(i32), i32, C.POINTER(vp)]
+            L.hpt_group_destroy.argtypes = [vp]
+            L.hpt_group_last_error.argtypes = [vp]; L.hpt_group_last_error.restype = C.c_char_p
+            L.hpt_group_size.argtypes = [vp]
+            L.hpt_group_ctx.argtypes = [vp, i32]; L.hpt_group_ctx.restype = vp
+            L.hpt_group_frame.argtypes = [vp, i32]; L.hpt_group_frame.restype = vp
+            L.hpt_group_set_sharding.argtypes = [vp, i32]
+            L.hpt_group_upload_triangles.argtypes = [vp, vp, i32]
+            L.hpt_group_upload_bvh.argtypes = [vp, vp, vp, i32]
+            L.hpt_group_set_scene.argtypes = [vp, vp, i32, vp, i32]
+            L.hpt_group_set_camera.argtypes = [vp, vp]
+            L.hpt_group_set_config.argtypes = [vp, C.POINTER(Config)]
+            L.hpt_group_render.argtypes = [vp, i32, i32]
+            L.hpt_group_synchronize.argtypes = [vp]
+            L.hpt_group_read_image.argtypes = [vp, vp]
+            L.hpt_group_get_stats.argtypes = [vp, C.POINTER(Stats)]
+            L.hpt_checkpoint_save.argtypes = [vp, vp, i32, C.c_char_p]
+            L.hpt_checkpoint_load.argtypes = [vp, vp, C.POINTER(i32), C.c_char_p]
         L.hpt_primary_hits.argtypes = [vp, i32, vp, vp]
         L.hpt_slab_floats.argtypes = [vp]; L.hpt_slab_floats.restype = C.c_int64
         L.hpt_pack_tiles.argtypes = [vp, vp, vp]
@@ -81,6 +112,8 @@ def lib():
         L.hpt_host_save_ppm.argtypes = [vp, i32, i32, C.c_char_p]
         L.hpt_host_save_png_rgb8.argtypes = [vp, i32, i32, C.c_char_p]
         L.hpt_pathtracer_new.argtypes = [i32, i32, i32]; L.hpt_pathtracer_new.restype = vp
+        if not os.environ.get("HPT_LIB") or hasattr(L, "hpt_pathtracer_new_group"):
+            L.hpt_pathtracer_new_group.argtypes = [i32, i32, C.POINTER(i32), i32, i32]; L.hpt_pathtracer_new_group.restype = vp
         L.hpt_pathtracer_delete.argtypes = [vp]
         L.hpt_pathtracer_error.argtypes = [vp]; L.hpt_pathtracer_error.restype = C.c_char_p
         for n in ("set_scene_default", "set_camera_default", "get_iterations", "get_width", "get_height"):
@@ -270,6 +303,39 @@ class Backend:
     def unpack_tiles(self, d_slabs, d_image):
         self._chk(self.L.hpt_unpack_tiles(self.h, C.c_void_p(d_slabs), C.c_void_p(d_image)))
 
+    # multi-GPU exchange inside the library (RCCL called from C++), one process per GPU
+    def comm_unique_id(self):
+        """-> the 128 bytes rank 0 hands to the other ranks (hpt_comm_unique_id)."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.L.hpt_comm_unique_id(buf)
+        if rc != 0:
+            raise HptError("hpt_comm_unique_id: %s" % self.L.hpt_last_error(None).decode(), rc)
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._chk(self.L.hpt_comm_init(self.h, C.c_char_p(unique_id), rank, world))
+
+    def comm_destroy(self):
+        self._chk(self.L.hpt_comm_destroy(self.h))
+
+    def gather_tiles(self, d_image):
+        """pack -> ncclAllGather -> unpack on the context's stream: every rank ends with the whole frame."""
+        self._chk(self.L.hpt_gather_tiles(self.h, C.c_void_p(d_image)))
+
+    def reduce_samples(self, d_image, d_frame, n_local, n_total):
+        """d_frame = sum over ranks of (n_r / n_total) * image_r (one ncclAllReduce); d_frame may be d_image."""
+        self._chk(self.L.hpt_reduce_samples(self.h, C.c_void_p(d_image), C.c_void_p(d_frame), n_local, n_total))
+
+    def checkpoint_save(self, d_image, spp_done, path):
+        self._chk(self.L.hpt_checkpoint_save(self.h, C.c_void_p(d_image), spp_done, os.fsencode(path)))
+
+    def checkpoint_load(self, d_image, path):
+        """Fills d_image from the file; -> the number of iterations folded into it."""
+        n = C.c_int(0)
+        self._chk(self.L.hpt_checkpoint_load(self.h, C.c_void_p(d_image), C.byref(n), os.fsencode(path)))
+        return n.value
+
     def tonemap(self, d_image, d_rgb8, n_pixels):
         self._chk(self.L.hpt_tonemap(self.h, C.c_void_p(d_image), C.c_void_p(d_rgb8), n_pixels))
 
@@ -282,15 +348,90 @@ class Backend:
         return s.as_dict()
 
 
+class Group:
+    """One hpt_group: one process driving several GPUs (a context, a stream and a device image per GPU, one RCCL
+    communicator over them; hpt_group_* in include/hpt/hpt.h)."""
+
+    def __init__(self, width, height, devices):
+        self.L = lib()
+        devs = (C.c_int * len(devices))(*devices)
+        g = C.c_void_p()
+        rc = self.L.hpt_group_create(width, height, devs, len(devices), C.byref(g))
+        if rc != 0:
+            raise HptError("hpt_group_create: %s" % self.L.hpt_group_last_error(None).decode(), rc)
+        self.g = g
+        self.width, self.height, self.n = width, height, len(devices)
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.hpt_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HptError("hpt error %d: %s" % (rc, self.L.hpt_group_last_error(self.g).decode()), rc)
+
+    def set_sharding(self, mode):
+        self._chk(self.L.hpt_group_set_sharding(self.g, mode))
+
+    def load(self, scn, bvh=None):
+        if bvh is None:
+            bvh = build_bvh(scn["verts"])
+        bbox = np.ascontiguousarray(bvh["bbox"], BBOX); info = np.ascontiguousarray(bvh["info"], INFO)
+        tris = np.ascontiguousarray(bvh["triangles"], TRIANGLE)
+        pr = np.ascontiguousarray(scn["primitives"], PRIMITIVE); mt = np.ascontiguousarray(scn["materials"], MATERIAL)
+        cam = np.ascontiguousarray(scn["camera"], CAMERA).reshape(1)
+        cfg = scn["cfg"]
+        c = Config(int(cfg["max_depth"]), int(cfg["rr_start"]), float(cfg["diffuse_scale"]), int(cfg["seed"]))
+        self._chk(self.L.hpt_group_upload_bvh(self.g, _p(bbox), _p(info), len(bbox)))
+        self._chk(self.L.hpt_group_upload_triangles(self.g, _p(tris), len(tris)))
+        self._chk(self.L.hpt_group_set_scene(self.g, _p(pr), len(pr), _p(mt), len(mt)))
+        self._chk(self.L.hpt_group_set_camera(self.g, _p(cam)))
+        self._chk(self.L.hpt_group_set_config(self.g, C.byref(c)))
+        return bvh
+
+    def render(self, spp_begin, spp_end):
+        self._chk(self.L.hpt_group_render(self.g, spp_begin, spp_end))
+
+    def synchronize(self):
+        self._chk(self.L.hpt_group_synchronize(self.g))
+
+    def read_image(self):
+        img = np.empty((self.height * self.width, 3), np.float32)
+        self._chk(self.L.hpt_group_read_image(self.g, _p(img)))
+        return img
+
+    def frame(self, member):
+        """Device address of a member's frame (width*height*3 floats)."""
+        return self.L.hpt_group_frame(self.g, member)
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.hpt_group_get_stats(self.g, C.byref(s)))
+        return s.as_dict()
+
+
 class Pathtracer:
     """The C++ facade (host/pathtracer.hpp) with the reference's method names
     (reference pathtracer/pathtracer.hpp:55-76)."""
 
-    def __init__(self, w, h, device=0):
+    def __init__(self, w, h, device=0, devices=None, sample_shards=False):
         self.L = lib()
-        self.p = self.L.hpt_pathtracer_new(w, h, device)
-        if not self.p:
-            raise HptError("Pathtracer: %s" % self.L.hpt_last_error(None).decode())
+        if devices is not None:                 # several GPUs behind the same facade (hpt_group)
+            devs = (C.c_int * len(devices))(*devices)
+            self.p = self.L.hpt_pathtracer_new_group(w, h, devs, len(devices), int(sample_shards))
+            if not self.p:
+                raise HptError("Pathtracer: %s" % self.L.hpt_group_last_error(None).decode())
+        else:
+            self.p = self.L.hpt_pathtracer_new(w, h, device)
+            if not self.p:
+                raise HptError("Pathtracer: %s" % self.L.hpt_last_error(None).decode())
         self.w, self.h = w, h
 
     def close(self):

@@ -88,6 +88,13 @@ void *hpt_pathtracer_new(int w, int h, int device) {
     if (!p->ok()) { delete p; return nullptr; }
     return p;
 }
+// several devices behind the same facade (hpt_group); NULL on failure, text in hpt_group_last_error(NULL)
+void *hpt_pathtracer_new_group(int w, int h, const int *devices, int n_devices, int sample_shards) {
+    if (!devices || n_devices < 1) return nullptr;
+    Pathtracer *p = new Pathtracer(w, h, std::vector<int>(devices, devices + n_devices), sample_shards != 0);
+    if (!p->ok()) { delete p; return nullptr; }
+    return p;
+}
 void hpt_pathtracer_delete(void *p) { delete (Pathtracer *)p; }
 const char *hpt_pathtracer_error(void *p) { return ((Pathtracer *)p)->error(); }
 int hpt_pathtracer_set_scene_default(void *p) { return ((Pathtracer *)p)->set_scene(); }

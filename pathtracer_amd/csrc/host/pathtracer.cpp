@@ -25,12 +25,24 @@ Pathtracer::Pathtracer(int w, int h, int device) : width(w), height(h) {
     sample_data.assign((size_t)w * h, Pixel{0, 0, 0});
 }
 
-Pathtracer::~Pathtracer() {
-    if (d_image) (void)hipFree(d_image);
-    hpt_destroy(ctx);
+Pathtracer::Pathtracer(int w, int h, const std::vector<int> &devices, bool sample_shards) : width(w), height(h) {
+    if (hpt_group_create(w, h, devices.data(), (int)devices.size(), &group) != HPT_OK) { create_error = hpt_group_last_error(nullptr); group = nullptr; return; }
+    if (sample_shards && hpt_group_set_sharding(group, HPT_SHARD_SAMPLES) != HPT_OK) {
+        create_error = hpt_group_last_error(group);
+        hpt_group_destroy(group); group = nullptr;
+        return;
+    }
+    ctx = hpt_group_ctx(group, 0);
+    image_data.assign((size_t)w * h, Pixel{0, 0, 0});
 }
 
-const char *Pathtracer::error() const { return ctx ? hpt_last_error(ctx) : create_error.c_str(); }
+Pathtracer::~Pathtracer() {
+    if (d_image) (void)hipFree(d_image);
+    if (group) hpt_group_destroy(group);          // destroys its members, ctx among them
+    else hpt_destroy(ctx);
+}
+
+const char *Pathtracer::error() const { return group ? hpt_group_last_error(group) : ctx ? hpt_last_error(ctx) : create_error.c_str(); }
 
 // The reference's fixed scene (pathtracer.cpp:322-382): one diffuse material, two
 // dead planes (type 4), a light sphere and two spheres.
@@ -60,6 +72,7 @@ int Pathtracer::set_scene() {
 
 int Pathtracer::set_scene(const std::vector<hpt_primitive> &prims, const std::vector<hpt_material> &mats) {
     if (!ctx) return 0;
+    if (group) return hpt_group_set_scene(group, prims.data(), (int)prims.size(), mats.data(), (int)mats.size()) == HPT_OK;
     return hpt_set_scene(ctx, prims.data(), (int)prims.size(), mats.data(), (int)mats.size()) == HPT_OK;
 }
 
@@ -73,11 +86,13 @@ int Pathtracer::set_camera() {
 
 int Pathtracer::set_camera(const hpt_camera &cam) {
     if (!ctx) return 0;
+    if (group) return hpt_group_set_camera(group, &cam) == HPT_OK;
     return hpt_set_camera(ctx, &cam) == HPT_OK;
 }
 
 int Pathtracer::set_config(const hpt_config &cfg) {
     if (!ctx) return 0;
+    if (group) return hpt_group_set_config(group, &cfg) == HPT_OK;
     return hpt_set_config(ctx, &cfg) == HPT_OK;
 }
 
@@ -89,15 +104,19 @@ int Pathtracer::set_triangles(std::vector<Vec3f> vertices) {
     for (size_t i = 0; i < vertices.size(); i += 3) vt.push_back(VectorTriangle(vertices[i], vertices[i + 1], vertices[i + 2]));
     bvh_constructor = BoundingVolumeHierarchy(std::move(vt));
     if (!bvh_constructor.buildTree()) return 0;
-    if (hpt_upload_bvh(ctx, bvh_constructor.get_bvh_bbox(), bvh_constructor.get_bvh_info(), bvh_constructor.get_n_nodes()) != HPT_OK) return 0;
     const std::vector<VectorTriangle> &ovt = bvh_constructor.get_triangles();
     triangles.resize(ovt.size());
     for (size_t i = 0; i < ovt.size(); i++) triangles[i] = create_triangle(ovt[i].v1, ovt[i].v2, ovt[i].v3);
+    if (group)
+        return hpt_group_upload_bvh(group, bvh_constructor.get_bvh_bbox(), bvh_constructor.get_bvh_info(), bvh_constructor.get_n_nodes()) == HPT_OK &&
+               hpt_group_upload_triangles(group, triangles.data(), (int)triangles.size()) == HPT_OK;
+    if (hpt_upload_bvh(ctx, bvh_constructor.get_bvh_bbox(), bvh_constructor.get_bvh_info(), bvh_constructor.get_n_nodes()) != HPT_OK) return 0;
     return hpt_upload_triangles(ctx, triangles.data(), (int)triangles.size()) == HPT_OK;
 }
 
 Pixel *Pathtracer::render() {
     if (!ctx) return nullptr;
+    if (group) return render(1);
     if (hpt_render_sample(ctx, iterations, &image_data[0].red) != HPT_OK) return nullptr;
     iterations++;
     return image_data.data();
@@ -105,6 +124,12 @@ Pixel *Pathtracer::render() {
 
 Pixel *Pathtracer::render(int n) {
     if (!ctx || n <= 0) return nullptr;
+    if (group) {                      // every member renders its shard into its own device image; the exchange completes the frame
+        if (hpt_group_render(group, iterations, iterations + n) != HPT_OK) return nullptr;
+        if (hpt_group_read_image(group, &image_data[0].red) != HPT_OK) return nullptr;
+        iterations += n;
+        return image_data.data();
+    }
     size_t bytes = image_data.size() * sizeof(Pixel);
     if (!d_image && hipMalloc((void **)&d_image, bytes) != hipSuccess) return nullptr;
     if (hipMemcpy(d_image, image_data.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
@@ -119,7 +144,7 @@ Pixel *Pathtracer::render(int n) {
 // device-resident state: hpt_first_bounce caches bounce 0, every iterative_render() advances each pixel's
 // path by one bounce, reconstruct() folds the paths that ended into the per-pixel running mean.
 void Pathtracer::iterative_render_first_bounce() {       // reference pathtracer.cpp:117-157
-    if (!ctx) return;
+    if (!ctx || group) return;                           // the live loop runs on one device
     size_t bytes = image_data.size() * sizeof(Pixel);
     if (!d_image && hipMalloc((void **)&d_image, bytes) != hipSuccess) return;
     if (hipMemset(d_image, 0, bytes) != hipSuccess) return;
@@ -128,7 +153,7 @@ void Pathtracer::iterative_render_first_bounce() {       // reference pathtracer
 }
 
 void Pathtracer::iterative_render() {                    // reference pathtracer.cpp:159-176
-    if (!ctx) return;
+    if (!ctx || group) return;
     (void)hpt_bounce(ctx);
 }
 

@@ -16,6 +16,10 @@ typedef hpt_pixel Pixel;
 class Pathtracer {
 public:
     Pathtracer(int w, int h, int device = 0);
+    // Several GPUs behind the same facade ("multi-GPU handled inside the context"): an hpt_group over
+    // `devices` -- tile shards and one all-gather per render() (bit-identical images for any number of devices), or
+    // with sample_shards iterations s % n == member and one all-reduce.  The live-loop calls need a single device.
+    Pathtracer(int w, int h, const std::vector<int> &devices, bool sample_shards = false);
     ~Pathtracer();
     Pathtracer(const Pathtracer &) = delete;             // owns the backend context and the device image
     Pathtracer &operator=(const Pathtracer &) = delete;
@@ -51,10 +55,12 @@ public:
     int get_height() const { return height; }
     int get_iterations() const { return iterations; }
     Pixel *get_image() { return image_data.data(); }
-    hpt_ctx *backend() { return ctx; }
+    hpt_ctx *backend() { return ctx; }                  // (member 0 of a group)
+    hpt_group *backend_group() { return group; }
 
 private:
     hpt_ctx *ctx = nullptr;
+    hpt_group *group = nullptr;              // several devices: owns the contexts (ctx = member 0, not to be destroyed by itself)
     int width, height, iterations = 0;
     std::vector<Pixel> image_data, sample_data;
     std::vector<hpt_triangle> triangles;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/hpt/hpt.h"
+#include "hpt_internal.h"
 #include "render_kernels.h"
 #include "host/bvh.hpp"            // parallel_chunks, build_threads
 
@@ -146,8 +147,24 @@ struct hpt_ctx {
     IterState iter{};
     int iter_ready = 0;              // 1 after hpt_first_bounce
     int iter_pending = 0;            // 1 between hpt_bounce and hpt_reconstruct_paths
+    hpt_comm *comm = nullptr;        // communicator of the multi-GPU exchange (hpt_comm.hip), released by hpt_destroy
     std::string err;
 };
+
+// ---- hpt_internal.h: what the library's other translation units see of a context ----
+int hpt_internal_fail(hpt_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+hpt_ctx_view hpt_internal_view(const hpt_ctx *c) {
+    return hpt_ctx_view{c->device, c->width, c->height, c->stream, c->rank, c->world, c->sample_rank, c->sample_world, c->cfg};
+}
+hpt_comm *&hpt_internal_comm(hpt_ctx *ctx) { return ctx->comm; }
 
 namespace {
 
@@ -564,6 +581,7 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
 int hpt_destroy(hpt_ctx *ctx) {
     if (!ctx) return HPT_OK;
     (void)hipSetDevice(ctx->device);
+    (void)hpt_comm_destroy(ctx);
     (void)hipFree(ctx->d_nodes); (void)hipFree(ctx->d_tris); (void)hipFree(ctx->d_prims); (void)hipFree(ctx->d_mats);
     (void)hipFree(ctx->d_work); (void)hipFree(ctx->d_counters); (void)hipFree(ctx->d_sample); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_hit_id); (void)hipFree(ctx->d_hit_t); (void)hipFree(ctx->d_spill); (void)hipFree(ctx->d_samples);

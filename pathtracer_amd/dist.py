@@ -110,17 +110,60 @@ class Exchange:
             be.synchronize()
         return self.image
 
-    def reduce(self, n_local, n_total):
-        """Sample shards: this rank's running mean over its n_local samples -> the frame's mean (ONE all-reduce)."""
+    def reduce(self, n_local, n_total, frame=None):
+        """Sample shards: this rank's running mean over its n_local samples -> the frame's mean (ONE all-reduce).
+        In place by default; with `frame` (a tensor like image) the rank's own mean is kept -- what a progressive
+        render needs, which goes on folding samples into it and reduces again every K iterations."""
+        import torch
+        out = self.image if frame is None else frame
         if self.gloo:
             self.backend.synchronize()
             host = self.image.cpu()
             reduce_samples(host, n_local, n_total, group=self.group)
-            self.image.copy_(host)
-            return self.image
-        if not self._stream_ordered():
+            out.copy_(host)
+            torch.cuda.current_stream().synchronize()
+            return out
+        ordered = self._stream_ordered()
+        if not ordered:
             self.backend.synchronize()
-        return reduce_samples(self.image, n_local, n_total, group=self.group)
+        if frame is not None:
+            frame.copy_(self.image)
+        reduce_samples(out, n_local, n_total, group=self.group)
+        if not ordered:
+            torch.cuda.current_stream().synchronize()      # the backend's own stream may write the image next
+        return out
+
+
+class NativeExchange:
+    """The same two exchanges through the library's own communicator (hpt_comm_init / hpt_gather_tiles /
+    hpt_reduce_samples: RCCL called from C++, queued on the backend's stream, slab buffers owned by the context).
+    torch.distributed only carries the 128-byte unique id from rank 0 to the others; with world == 1 it is not
+    needed at all (a one-rank communicator: what the one-GPU box can execute of this path)."""
+
+    def __init__(self, backend, image, world, rank=0, group=None):
+        import torch
+        self.backend, self.image, self.world, self.rank = backend, image, world, rank
+        if world > 1:
+            import torch.distributed as dist
+            uid = backend.comm_unique_id() if rank == 0 else bytes(128)
+            t = torch.frombuffer(bytearray(uid), dtype=torch.uint8).clone()
+            on_device = dist.get_backend(group) == "nccl"
+            if on_device:
+                t = t.to(image.device)
+            dist.broadcast(t, src=0, group=group)
+            uid = bytes(t.cpu().numpy().tobytes())
+        else:
+            uid = backend.comm_unique_id()
+        backend.comm_init(uid, rank, world)
+
+    def gather(self):
+        self.backend.gather_tiles(self.image.data_ptr())
+        return self.image
+
+    def reduce(self, n_local, n_total, frame=None):
+        out = self.image if frame is None else frame
+        self.backend.reduce_samples(self.image.data_ptr(), out.data_ptr(), n_local, n_total)
+        return out
 
 
 def gather_image(backend, image, world, group=None):
@@ -129,7 +172,8 @@ def gather_image(backend, image, world, group=None):
     if world == 1:
         return image
     ex = getattr(backend, "_exchange", None)
-    if ex is None or ex.image.data_ptr() != image.data_ptr() or ex.world != world or ex.group is not group:
+    # keyed on the tensor itself: the caching allocator may hand a later tensor (another size, another device) the same address
+    if ex is None or ex.image is not image or ex.world != world or ex.group is not group:
         ex = backend._exchange = Exchange(backend, image, world, group)
     return ex.gather()
 

@@ -2,12 +2,16 @@
 the place of the reference's GLUT viewer (main.cpp:92-151; its 'p' key, main.cpp:194-203, becomes --out).
 
     python -m pathtracer_amd.render --obj model.obj --w 512 --h 512 --spp 64 --out out.png
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m pathtracer_amd.render --obj ... --out out.png
+    python -m pathtracer_amd.render --gpus 8 --obj ... --out out.png          (starts the 8 ranks itself)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m pathtracer_amd.render --gpus 8 --obj ... --out out.png
 
 One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher); scene and BVH are built by every rank
 (replicated); --shard tiles (default: 8x8 tiles round-robin, one all-gather, image bit-identical
 for any number of GPUs) or samples (iterations s % N == rank, one all-reduce of weighted running means, within
-1e-5 relative).  Rank 0 writes the image.  Scene set-up follows hpt_cli: reference default scene and camera, or
+1e-5 relative).  Rank 0 writes the image.  --reduce-every K renders progressively: K-iteration slices with the exchange after each
+(every rank then holds the frame so far; --preview writes it after every slice).  --checkpoint FILE saves the
+accumulation buffer and its sample count after every slice (per rank: FILE.rankR for N > 1), --resume continues from it:
+in tile mode bit-identically to a render that was never stopped.  Scene set-up follows hpt_cli: reference default scene and camera, or
 one emissive sphere with --light; --scene NAME renders one of the bench scenes (pathtracer_amd/scenes.py).
 """
 import argparse
@@ -46,7 +50,26 @@ def main(argv=None):
                     help="replace the default primitives by one emissive sphere (triangles cannot emit)")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "samples"])
     ap.add_argument("--out", default="out.png", help=".png or .ppm")
+    ap.add_argument("--gpus", type=int, default=0, help="number of GPUs (ranks); without a launcher the ranks are started here")
+    ap.add_argument("--reduce-every", type=int, default=0, metavar="K", help="progressive: exchange after every K iterations")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="torch.distributed collectives, or the library's own communicator (RCCL called from C++)")
+    ap.add_argument("--checkpoint", help="file for the accumulation buffer + sample count, written after every slice")
+    ap.add_argument("--resume", action="store_true", help="continue from --checkpoint if it exists")
+    ap.add_argument("--preview", action="store_true", help="with --reduce-every: write --out after every slice")
+    ap.add_argument("--stop-after", type=int, default=0, metavar="S", help="stop once S iterations are done (testing --resume)")
     a = ap.parse_args(argv)
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks before anything here touches the GPU; rank 0 prints the line, the exit status is the launcher's
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        args = list(sys.argv[1:] if argv is None else argv)
+        return subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pathtracer_amd.render"] + args)
 
     import torch
     import torch.distributed as dist
@@ -56,6 +79,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus and a.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("pathtracer_amd.render needs a GPU: the render path has no CPU fallback")
     # HPT_DIST_BACKEND=gloo rehearses N>1 on a box with fewer GPUs than ranks (ranks then share devices)
@@ -93,30 +118,67 @@ def main(argv=None):
     else:
         be.set_sample_shard(rank, world)
     image = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
-    t0 = time.perf_counter()
-    be.render(0, spp, image.data_ptr())
+    # sample shards rendered progressively: the rank's own running mean must survive each reduction
+    frame = torch.zeros_like(image) if (a.shard == "samples" and world > 1 and a.reduce_every) else image
+    exchange = None
     if world > 1:
-        exchange = pdist.Exchange(be, image, world)
+        exchange = pdist.NativeExchange(be, image, world, rank) if a.exchange == "native" else pdist.Exchange(be, image, world)
+    ckpt = None
+    if a.checkpoint:
+        ckpt = a.checkpoint if world == 1 else "%s.rank%d" % (a.checkpoint, rank)
+    done = 0
+    if a.resume and ckpt and os.path.exists(ckpt):
+        done = be.checkpoint_load(image.data_ptr(), ckpt)      # refuses another size, config or shard
+    if a.resume and ckpt and world > 1:
+        # the slices are collective: every rank must continue at the same iteration
+        lohi = torch.tensor([done, -done], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(lohi, op=dist.ReduceOp.MAX)
+        if int(lohi[0]) != -int(lohi[1]):
+            raise SystemExit("the ranks' checkpoints disagree (%d..%d iterations done): remove them or restore a matching set"
+                             % (-int(lohi[1]), int(lohi[0])))
+
+    def write(path):
+        rgb = frame.cpu().numpy().reshape(h, w, 3)
+        if path.endswith(".ppm"):
+            if api.lib().hpt_host_save_ppm(api._p(np.ascontiguousarray(rgb)), w, h, os.fsencode(path)) != 0:
+                raise SystemExit("cannot write %s" % path)
+        else:
+            api.save_png(rgb, path)
+
+    t0 = time.perf_counter()
+    K = a.reduce_every if a.reduce_every > 0 else spp
+    target = min(spp, a.stop_after) if a.stop_after else spp
+    n_rays = 0
+    while done < target:
+        nxt = min(done + K, target)
+        be.render(done, nxt, image.data_ptr())
+        if ckpt:
+            # this rank's own accumulation (before the exchange overwrites the other ranks' tiles: they save theirs)
+            be.checkpoint_save(image.data_ptr(), nxt, ckpt)
+        if exchange is not None:
+            if a.shard == "tiles":
+                exchange.gather()
+            else:
+                exchange.reduce(pdist.sample_shard_count(0, nxt, rank, world), nxt, None if frame is image else frame)
+        st = be.stats()                                       # (waits for the slice)
+        n_rays += st["rays_primary"] + st["rays_bounce"]
+        done = nxt
+        if a.preview and a.reduce_every and rank == 0:
+            write(a.out)
+    if exchange is not None and n_rays == 0 and done > 0:      # resumed from a finished checkpoint: it holds this rank's part only
         if a.shard == "tiles":
             exchange.gather()
         else:
-            exchange.reduce(pdist.sample_shard_count(0, spp, rank, world), spp)
+            exchange.reduce(pdist.sample_shard_count(0, done, rank, world), done, None if frame is image else frame)
     be.synchronize()
     torch.cuda.synchronize()
     t_render = time.perf_counter() - t0
-    st = be.stats()
-    rays = torch.tensor([float(st["rays_primary"] + st["rays_bounce"])], dtype=torch.float64,
-                        device="cuda" if backend == "nccl" else "cpu")
+    rays = torch.tensor([float(n_rays)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(rays)
     if rank == 0:
-        rgb = image.cpu().numpy().reshape(h, w, 3)
-        if a.out.endswith(".ppm"):
-            if api.lib().hpt_host_save_ppm(api._p(np.ascontiguousarray(rgb)), w, h, os.fsencode(a.out)) != 0:
-                raise SystemExit("cannot write %s" % a.out)
-        else:
-            api.save_png(rgb, a.out)
-        print(json.dumps({"triangles": int(len(bvh["triangles"])), "width": w, "height": h, "spp": spp, "gpus": world,
+        write(a.out)
+        print(json.dumps({"triangles": int(len(bvh["triangles"])), "width": w, "height": h, "spp": done, "gpus": world,
                           "shard": a.shard, "bvh_s": round(t_bvh, 4), "render_s": round(t_render, 4),
                           "rays": float(rays[0]), "out": a.out}))
     if world > 1:
