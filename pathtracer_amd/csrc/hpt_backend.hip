@@ -27,6 +27,7 @@ std::string g_create_error;
 
 constexpr int kMaxTreeDepth = 64;   // the reference's own bound: int todo[64], ray_kernel.cl:389
 constexpr int kBlock = 256;
+constexpr int kLdsTopMax = 1024;    // nodes of the top of the tree that are numbered first, breadth first (hpt_upload_bvh); render_kernel keeps a prefix in LDS
 #define HPT_N_COUNTERS 16
 #define HPT_COUNTER_LOADS 15        // render_kernels.h: 16-B lane-loads
 
@@ -95,6 +96,11 @@ struct hpt_ctx {
     int root_ref_tris = HPT_REF_DONE;
     float4 *d_pairs = nullptr;
     bool pairs_dirty = true;
+    // Upload generations: a scene REPLACED in a resident context arrives as two uploads, and building the records after the
+    // first would pair the new half with the old one, only to be thrown away by the second (1.26 GB of records at C4).  An
+    // upload builds eagerly only when the other half is newer than the last build; otherwise the build waits for the other
+    // upload or for the next render.
+    unsigned tris_gen = 0, bvh_gen = 0, built_tris_gen = 0, built_bvh_gen = 0;
     bool singles = false;            // record form of the current tree: one triangle per 48-B record (ensure_pairs)
     size_t tree_bytes = 0;           // nodes + triangle records of the current tree as the traversal reads them (ensure_pairs)
     int leaf_records = 0;            // HPT_LEAF_RECORDS: 0 = per tree, 1 = singles, 2 = pairs
@@ -135,13 +141,17 @@ struct hpt_ctx {
     int fetch_chunk = 256;           // work items a WAVE reserves per atomic; its lanes take them in order (HPT_FETCH_CHUNK overrides)
     int tail_chunks = 4;             // the last tail_chunks x waves x fetch_chunk work items of a launch are reserved 64 at a time (HPT_TAIL_CHUNKS; 2/4/8/16: 701.8/700.7/700.5/700.6 ms at C3)
     int fetch_threshold = 32;        // iter_trace_kernel's FETCH step threshold (HPT_FETCH_THRESHOLD overrides)
-    int stack_cap = 10;              // LDS stack entries per lane of render_kernel (HPT_STACK_CAP overrides)
+    int stack_cap = 0;               // LDS stack entries per lane of the persistent kernels; 0 = per tree (stack_cap_of()), HPT_STACK_CAP fixes it
     uint2 *d_spill = nullptr;        // HBM overflow of the traversal stack
     size_t spill_bytes = 0;
     float *d_samples = nullptr;      // [iteration in batch][pixel slot][3] radiance samples of one launch
     size_t samples_bytes = 0;
     size_t sample_budget_bytes = (size_t)HPT_SAMPLE_BUDGET_DEFAULT_MB << 20;   // HPT_SAMPLE_BUDGET_MB overrides; bounds the paths per launch
     int blocks_per_cu_cap = 0;       // 0 = occupancy limit (HPT_BLOCKS_PER_CU overrides)
+    size_t extra_lds = 0;            // LDS a launch wants behind its stacks (render_kernel's copy of the top of the tree)
+    int lds_top = -1;                // nodes of the top of the tree that render_kernel keeps in LDS: -1 = as many as fit beside the stacks at the
+                                     // kernel's occupancy (C3: 104 beside eight stack entries per lane at 7 blocks per CU); HPT_LDS_TOP_NODES fixes it (0 = none)
+    size_t lds_per_cu = 160 << 10;
     bool count_loads = false;        // HPT_COUNT_LANE_LOADS=1: renders run the counting instantiation of render_kernel (hpt_stats.lane_loads)
     void *d_iter = nullptr;          // per-pixel state of the iterative pipeline (one allocation), made by hpt_first_bounce
     IterState iter{};
@@ -221,6 +231,9 @@ int slab_tiles(const hpt_ctx *c) { return (n_tiles(c) + c->world - 1) / c->world
 // re-pointed at them.  Leaves are numbered in node order, so a near-first descent walks the records forward.
 // Record form, per tree: two consecutive triangles of a leaf per 80 B, or -- when the leaves hold fewer than
 // 1.25 triangles on average (HPT_LEAF_RECORDS=pairs|singles overrides) -- one triangle per 48 B.
+typedef void (*render_fn)(const RenderParams);
+int choose_render(hpt_ctx *ctx, render_fn &fn, uint32_t &n_lds_nodes);
+
 int ensure_pairs(hpt_ctx *ctx) {
     if (!ctx->pairs_dirty) return HPT_OK;
     if (ctx->root_ref_tris == HPT_REF_DONE) { ctx->pairs_dirty = false; return HPT_OK; }     // no tree
@@ -277,11 +290,10 @@ int ensure_pairs(hpt_ctx *ctx) {
     ctx->singles = singles;
     ctx->tree_bytes = wide.size() * sizeof(WideNode) + rec.size() * sizeof(float);
     ctx->pairs_dirty = false;
-    return HPT_OK;
+    ctx->built_tris_gen = ctx->tris_gen; ctx->built_bvh_gen = ctx->bvh_gen;
+    render_fn fn; uint32_t n_top;
+    return choose_render(ctx, fn, n_top);      // attribute and occupancy queries now, not inside the first render call
 }
-
-constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
-constexpr size_t kPairFetchTreeBytes = (size_t)1 << 30;       // helper-lane node fetch: measured to pay at 1.26 GB, to cost 1-3 % at 378 MB
 
 int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, int spp_end, int raw) {
     if (!ctx->have_camera) return fail(ctx, HPT_ERR_INVALID, "hpt_set_camera has not been called");
@@ -326,6 +338,16 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     return HPT_OK;
 }
 
+constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
+constexpr size_t kPairFetchTreeBytes = (size_t)1 << 30;       // helper-lane node fetch: measured to pay at 1.26 GB, to cost 1-3 % at 378 MB
+
+// LDS stack entries per lane.  Cache-resident trees: 8, which leaves room for 104 nodes of the tree's top in LDS at 7 blocks
+// per CU (8 + 104 beat 10 + 40 and 9 + 72 at C3; without the node copy 8, 9 and 10 tie: profiles/r03/lds_top/).  Trees that
+// stream from HBM keep 10 and no node copy: at C4 every entry that overflows to HBM is one more miss in a kernel that waits
+// for misses (cap 8: -3.3 %; with the node copy on top: -6 %).
+bool streaming_tree(const hpt_ctx *ctx) { return ctx->tree_bytes > kStreamingTreeBytes; }
+int stack_cap_of(const hpt_ctx *ctx) { return ctx->stack_cap > 0 ? ctx->stack_cap : streaming_tree(ctx) ? 10 : 8; }
+
 size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
     int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
     return (size_t)depth * block * sizeof(uint2);
@@ -352,6 +374,47 @@ int kernel_shape(hpt_ctx *ctx, const void *kernel, size_t lds, int &blocks_per_c
     return HPT_OK;
 }
 
+// The instantiation of render_kernel that renders the resident scene, and the number of nodes of the tree's top that it
+// keeps in LDS.  Asked at every render and once when a scene becomes resident (ensure_pairs(), hpt_set_scene), so that the
+// attribute and occupancy queries of kernel_shape() are made outside the render calls (hpt_render_noalloc: "calls no
+// allocating routine" -- the queries cache their answers in a host vector).
+int choose_render(hpt_ctx *ctx, render_fn &fn, uint32_t &n_lds_nodes) {
+    // one instantiation per (record form, counting build, long primitive list)
+    static const render_fn kRender[2][2][2] = {
+        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
+        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
+    // single-record trees of a gigabyte and more (short primitive lists): the instantiation whose NODE step fetches with helper lanes
+    static const render_fn kRenderPair[2] = {render_kernel<true, false, false, true>, render_kernel<true, true, false, true>};
+    const bool long_list = ctx->n_prims >= HPT_TWO_PHASE_MIN_PRIMS;
+    const bool pair_fetch = ctx->singles && !long_list &&
+                            (ctx->pair_fetch >= 0 ? ctx->pair_fetch != 0 : ctx->tree_bytes >= kPairFetchTreeBytes);
+    fn = pair_fetch ? kRenderPair[ctx->count_loads ? 1 : 0]
+                    : kRender[ctx->singles ? 1 : 0][ctx->count_loads ? 1 : 0][long_list ? 1 : 0];
+    // The top of the tree in LDS, behind the stacks: as many nodes as fit without costing the kernel a block per CU (LDS is
+    // handed out in 512-B granules: C3 at 7 blocks per CU and 8 stack entries per lane has room for 104 nodes; 105 and the
+    // seventh block is gone, -6 %, though the occupancy query still says 7).  C1 +3.6 %, C2 +2.0 %, C3 +4.9 %, C5 +-0;
+    // trees that stream from HBM get none (C4 -2.4 % with it: stack_cap_of()).
+    const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
+    const size_t stack_lds = (size_t)(stack_cap_of(ctx) < depth ? stack_cap_of(ctx) : depth) * kBlock * sizeof(uint2);
+    int per_cu = 0;
+    int rc = kernel_shape(ctx, (const void *)fn, stack_lds, per_cu);
+    if (rc) return rc;
+    if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
+    if (streaming_tree(ctx) && per_cu > 6) per_cu = 6;
+    long n_top = (ctx->lds_top < 0 && streaming_tree(ctx)) ? 0 : ctx->lds_top;
+    if (n_top < 0 && per_cu >= 1) n_top = ((long)((ctx->lds_per_cu / (size_t)per_cu) & ~(size_t)511) - (long)stack_lds) / (long)sizeof(WideNode);
+    if (n_top > ctx->n_wide) n_top = ctx->n_wide;
+    if (n_top > kLdsTopMax) n_top = kLdsTopMax;
+    if (n_top < 0 || ctx->root_ref < 0 || ctx->root_ref == HPT_REF_DONE) n_top = 0;
+    for (; n_top > 0; n_top -= 8) {                   // the occupancy query has the last word
+        int with_top = 0;
+        if ((rc = kernel_shape(ctx, (const void *)fn, stack_lds + (size_t)n_top * sizeof(WideNode), with_top))) return rc;
+        if (with_top >= per_cu) break;
+    }
+    n_lds_nodes = (uint32_t)(n_top > 0 ? n_top : 0);
+    return HPT_OK;
+}
+
 // Launch shape of a persistent traversal kernel (render_kernel, iter_trace_kernel): LDS for the capped
 // traversal stack, as many blocks as stay resident, HBM overflow of the stack sized for that grid.
 // noalloc: the overflow lives at the start of the device's static scratch array (and the grid shrinks until it
@@ -359,8 +422,8 @@ int kernel_shape(hpt_ctx *ctx, const void *kernel, size_t lds, int &blocks_per_c
 int prepare_persistent(hpt_ctx *ctx, const void *kernel, RenderParams &p, size_t &lds, long &blocks_max,
                        bool noalloc = false, size_t *scratch_used = nullptr) {
     const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
-    const int cap = ctx->stack_cap < depth ? ctx->stack_cap : depth;
-    lds = (size_t)cap * kBlock * sizeof(uint2);
+    const int cap = stack_cap_of(ctx) < depth ? stack_cap_of(ctx) : depth;
+    lds = (size_t)cap * kBlock * sizeof(uint2) + ctx->extra_lds;
     int per_cu = 0;
     int rc = kernel_shape(ctx, kernel, lds, per_cu);
     if (rc) return rc;
@@ -409,7 +472,8 @@ int render_events(hpt_ctx *ctx, int launch) {
 int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int raw, bool noalloc = false) {
     RenderParams p;
     if (noalloc && ctx->pairs_dirty && ctx->root_ref_tris != HPT_REF_DONE && ctx->max_leaf_end <= ctx->n_tris)
-        return fail(ctx, HPT_ERR_INVALID, "hpt_render_noalloc: the scene is not resident yet (upload the BVH and the triangles first)");
+        return fail(ctx, HPT_ERR_INVALID, "hpt_render_noalloc: the scene is not resident yet (upload the BVH and the triangles first; after replacing only one of "
+                                              "the two in a resident context, upload the other as well or call hpt_render once)");
     int rc = fill_params(ctx, p, d_image, spp_begin, spp_end, raw);
     if (rc) return rc;
     if (ctx->n_mats < 1 && ctx->root_ref != HPT_REF_DONE)
@@ -429,19 +493,13 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
 
     size_t lds; long blocks_max;
     size_t scratch_used = 0;
-    typedef void (*render_fn)(const RenderParams);
-    // one instantiation per (record form, counting build, long primitive list)
-    static const render_fn kRender[2][2][2] = {
-        {{render_kernel<false, false, false>, render_kernel<false, false, true>}, {render_kernel<false, true, false>, render_kernel<false, true, true>}},
-        {{render_kernel<true, false, false>, render_kernel<true, false, true>}, {render_kernel<true, true, false>, render_kernel<true, true, true>}}};
-    // single-record trees of a gigabyte and more (short primitive lists): the instantiation whose NODE step fetches with helper lanes
-    static const render_fn kRenderPair[2] = {render_kernel<true, false, false, true>, render_kernel<true, true, false, true>};
-    const bool long_list = ctx->n_prims >= HPT_TWO_PHASE_MIN_PRIMS;
-    const bool pair_fetch = ctx->singles && !long_list &&
-                            (ctx->pair_fetch >= 0 ? ctx->pair_fetch != 0 : ctx->tree_bytes >= kPairFetchTreeBytes);
-    const render_fn fn = pair_fetch ? kRenderPair[ctx->count_loads ? 1 : 0]
-                                    : kRender[ctx->singles ? 1 : 0][ctx->count_loads ? 1 : 0][long_list ? 1 : 0];
-    if ((rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max, noalloc, &scratch_used))) return rc;
+    render_fn fn; uint32_t n_top;
+    if ((rc = choose_render(ctx, fn, n_top))) return rc;
+    p.n_lds_nodes = n_top;
+    ctx->extra_lds = (size_t)n_top * sizeof(WideNode);
+    rc = prepare_persistent(ctx, (const void *)fn, p, lds, blocks_max, noalloc, &scratch_used);
+    ctx->extra_lds = 0;
+    if (rc) return rc;
 
     // paths (= 12-B samples) per launch: the sample buffer, and 32-bit work indices with headroom for the work
     // counter's overshoot (one chunk of <= 4096 per wave, < 2^16 waves)
@@ -553,6 +611,8 @@ int hpt_create(int width, int height, int device, hpt_ctx **out) {
     if (const char *e = getenv("HPT_STACK_CAP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->stack_cap = v; }
     if (const char *e = getenv("HPT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1) ctx->blocks_per_cu_cap = v; }
     if (const char *e = getenv("HPT_COUNT_LANE_LOADS")) ctx->count_loads = atoi(e) != 0;
+    if (const char *e = getenv("HPT_LDS_TOP_NODES")) { int v = atoi(e); if (v >= -1 && v <= kLdsTopMax) ctx->lds_top = v; }
+    if (prop.maxSharedMemoryPerMultiProcessor > 0) ctx->lds_per_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     size_t img = (size_t)width * height * 3 * sizeof(float);
     if ((e = hipMalloc((void **)&ctx->d_work, sizeof(unsigned int))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&ctx->d_counters, HPT_N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
@@ -623,7 +683,11 @@ int hpt_upload_triangles(hpt_ctx *ctx, const hpt_triangle *triangles, int n_tria
     ctx->n_tris = n_triangles;
     ctx->h_tris.assign(triangles, triangles + n_triangles);
     ctx->pairs_dirty = true;
-    return ensure_pairs(ctx);           // builds the traversal's records once tree and triangles are both here
+    ctx->tris_gen++;
+    // builds the traversal's records once tree and triangles are both here -- unless these triangles are the first half of a
+    // replacement (the tree is the one of the last build): then the new tree's upload builds, or the next render
+    if (ctx->built_bvh_gen == ctx->bvh_gen && ctx->built_tris_gen != 0) return HPT_OK;
+    return ensure_pairs(ctx);
 }
 
 // Depth-first reference arrays -> 64-B two-child nodes.  Interior node k of the
@@ -638,6 +702,7 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
     ctx->n_wide = 0; ctx->tree_depth = 0; ctx->max_leaf_end = 0; ctx->root_ref = HPT_REF_DONE; ctx->root_ref_tris = HPT_REF_DONE;
     ctx->h_wide.clear();
     ctx->pairs_dirty = true;
+    ctx->bvh_gen++;
     if (n_nodes == 0) return HPT_OK;
 
     auto leaf_ref = [&](int k, int &ref) -> int {
@@ -701,9 +766,35 @@ int hpt_upload_bvh(hpt_ctx *ctx, const hpt_bvh_bbox *bbox, const hpt_bvh_info *i
     ctx->root_ref = ctx->root_ref_tris;                  // "there is a tree"; ensure_pairs() re-points a leaf root
     ctx->root_lo[0] = bbox[0].minboundsx; ctx->root_lo[1] = bbox[0].minboundsy; ctx->root_lo[2] = bbox[0].minboundsz;
     ctx->root_hi[0] = bbox[0].maxboundsx; ctx->root_hi[1] = bbox[0].maxboundsy; ctx->root_hi[2] = bbox[0].maxboundsz;
+    if (ctx->root_ref_tris >= 0) {
+        // Number the top of the tree first, breadth first: any prefix of that order is "the top n nodes", which is what
+        // render_kernel copies to LDS.  Child references are explicit, so any numbering is a valid tree; the rest keeps its
+        // pre-order (a near-first descent still walks forward in memory there).
+        const int K = kLdsTopMax < n_wide ? kLdsTopMax : n_wide;
+        std::vector<int> order; order.reserve(n_wide);
+        std::vector<unsigned char> taken(n_wide, 0);
+        order.push_back(ctx->root_ref_tris); taken[ctx->root_ref_tris] = 1;
+        for (size_t head = 0; head < order.size() && (int)order.size() < K; head++)
+            for (int32_t ref : {wide[order[head]].ref0, wide[order[head]].ref1})
+                if (ref >= 0 && (int)order.size() < K) { order.push_back(ref); taken[ref] = 1; }
+        for (int i = 0; i < n_wide; i++) if (!taken[i]) order.push_back(i);
+        std::vector<int> new_of(n_wide);
+        for (int i = 0; i < n_wide; i++) new_of[order[i]] = i;
+        std::vector<WideNode> re(n_wide);
+        for (int i = 0; i < n_wide; i++) {
+            WideNode w = wide[order[i]];
+            if (w.ref0 >= 0) w.ref0 = new_of[w.ref0];
+            if (w.ref1 >= 0) w.ref1 = new_of[w.ref1];
+            re[i] = w;
+        }
+        wide.swap(re);
+        ctx->root_ref_tris = new_of[ctx->root_ref_tris];
+        ctx->root_ref = ctx->root_ref_tris;
+    }
     ctx->h_wide.swap(wide);                              // uploaded by ensure_pairs() with leaf references re-pointed
     ctx->n_wide = n_wide;
     ctx->tree_depth = depth_max;
+    if (ctx->built_tris_gen == ctx->tris_gen && ctx->built_bvh_gen != 0) return HPT_OK;   // first half of a replacement (see tris_gen)
     return ensure_pairs(ctx);           // (a no-op until the triangles the leaves name are uploaded too)
 }
 
@@ -734,6 +825,10 @@ int hpt_set_scene(hpt_ctx *ctx, const hpt_primitive *primitives, int n_primitive
     if ((rc = replace_buffer(ctx, ctx->d_prim_pairs, pairs.data(), pairs.size() * sizeof(PrimPair)))) return rc;
     if ((rc = replace_buffer(ctx, ctx->d_mats, materials, (size_t)n_materials * sizeof(hpt_material)))) return rc;
     ctx->n_prims = n_primitives; ctx->n_mats = n_materials;
+    if (!ctx->pairs_dirty && ctx->root_ref_tris != HPT_REF_DONE) {   // a long primitive list selects another instantiation: query it now
+        render_fn fn; uint32_t n_top;
+        return choose_render(ctx, fn, n_top);
+    }
     return HPT_OK;
 }
 

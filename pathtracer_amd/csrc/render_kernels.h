@@ -78,6 +78,8 @@ struct RenderParams {
     uint32_t tail_items;             // the last tail_items of a launch are reserved 64 at a time (scheduling only)
     int32_t singles;                 // record form of this tree (chosen per tree by the host, see HPT_SINGLE_*)
     int32_t fetch_threshold;         // iter_trace_kernel: lanes that must want a new ray before the wave fetches (scheduling only)
+    uint32_t n_lds_nodes;            // render_kernel: nodes 0 .. n_lds_nodes-1 (the top of the tree, breadth first: the host numbers them
+                                     // first) are copied to LDS by every block, behind its stacks, and read from there; 0 = none
 };
 
 struct Ray { f3 o, d; };
@@ -733,7 +735,7 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
 // per visit.  C4 +2.2 %; smaller trees lose 3-7 % to the three extra hops in front of every fetch (profiles/r02_tuning.md).
 template <bool COUNT, bool PAIR = false>
 __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill,
-                                                int n_in, unsigned long long &loads) {
+                                                int n_in, unsigned long long &loads, const float4 *lds_nodes = nullptr) {
     if (COUNT) loads += (unsigned)(n_in * 4);
     int n_now = n_in;
     for (;;) {
@@ -801,6 +803,15 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
             float4 X, Y, Z; int4 m;
             if (PAIR && pair_mode) {
                 X = pA; Y = pB; Z = pZ; m = pM;
+            } else if ((unsigned)s.cur < p.n_lds_nodes) {
+                // The top of the tree from this block's LDS copy (4 x ds_read_b128; n_lds_nodes = 0 where no copy is made):
+                // C3 -18.5 % vector-L1 lookups, TA busy 96.8 -> 91.4 %, its stalls on the cache 29 -> 19 % of that, frame -5 %
+                // (profiles/r03/lds_top/).  Node-major like the HBM array: one address, four instruction offsets (a
+                // quarter-major copy, conflict-free for lanes at consecutive nodes, was 1.5 % slower: three more address
+                // computations per visit).
+                const float4 *q = lds_nodes + ((unsigned)s.cur << 2);
+                X = q[0]; Y = q[1]; Z = q[2];
+                m = *reinterpret_cast<const int4 *>(q + 3);
             } else {
                 const unsigned node_off = (unsigned)s.cur << 6;
                 const float4 *q = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p.nodes) + node_off);
@@ -971,6 +982,11 @@ __global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? H
     tv.oxy = hpt_v2f{0, 0}; tv.ozix = hpt_v2f{0, 0}; tv.iyz = hpt_v2f{0, 0}; tv.rd = mk3(0, 0, 1);
     tv.t = 1000.0f; tv.hit = HPT_HIT_MISS; tv.cur = HPT_REF_DONE; tv.sp = 0; tv.flags = 0;
     uint2 *const spill = p.spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    // every block keeps the first n_lds_nodes nodes (the top of the tree, numbered first by the host) in LDS behind its
+    // traversal stacks: as many as fit beside them at this kernel's occupancy (launch_render())
+    float4 *const lds_nodes = reinterpret_cast<float4 *>(hpt_lds_stack + (size_t)p.stack_cap * blockDim.x);
+    for (unsigned i = threadIdx.x; i < p.n_lds_nodes * 4u; i += blockDim.x) lds_nodes[i] = reinterpret_cast<const float4 *>(p.nodes)[i];
+    __syncthreads();
 
     for (;;) {
         const bool wantS = tv.cur == HPT_REF_DONE;
@@ -1059,7 +1075,7 @@ __global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? H
         } else if (nT * p.tri_weight > nN * 4) {     // a lane in the TRI state counts tri_weight / 4 lanes in the NODE state
             trav_tri_steps<SINGLES, COUNT>(p, tv, stack, stride, spill, nT, n_loads);
         } else {
-            trav_node_steps<COUNT, PAIR>(p, tv, stack, stride, spill, nN, n_loads);
+            trav_node_steps<COUNT, PAIR>(p, tv, stack, stride, spill, nN, n_loads, lds_nodes);
         }
     }
     if (lane == 0u) {
