@@ -27,6 +27,7 @@ std::string g_create_error;
 
 constexpr int kMaxTreeDepth = 64;   // the reference's own bound: int todo[64], ray_kernel.cl:389
 constexpr int kBlock = 256;
+constexpr size_t kLdsGranule = 1280;  // LDS allocation granule per block (measured: choose_render())
 constexpr int kLdsTopMax = 1024;    // nodes of the top of the tree that are numbered first, breadth first (hpt_upload_bvh); render_kernel keeps a prefix in LDS
 #define HPT_N_COUNTERS 16
 #define HPT_COUNTER_LOADS 15        // render_kernels.h: 16-B lane-loads
@@ -391,8 +392,9 @@ int choose_render(hpt_ctx *ctx, render_fn &fn, uint32_t &n_lds_nodes) {
     fn = pair_fetch ? kRenderPair[ctx->count_loads ? 1 : 0]
                     : kRender[ctx->singles ? 1 : 0][ctx->count_loads ? 1 : 0][long_list ? 1 : 0];
     // The top of the tree in LDS, behind the stacks: as many nodes as fit without costing the kernel a block per CU (LDS is
-    // handed out in 512-B granules: C3 at 7 blocks per CU and 8 stack entries per lane has room for 104 nodes; 105 and the
-    // seventh block is gone, -6 %, though the occupancy query still says 7).  C1 +3.6 %, C2 +2.0 %, C3 +4.9 %, C5 +-0;
+    // handed out in granules of 1 280 B = 1/128 of the CU's 160 KB, which fits every observation of profiles/r03/lds_top/:
+    // 7 x 23 040 B and 8 x 20 480 B run, 7 x 23 296 B and 6 x 27 136 B lose a block; C3 at 7 blocks per CU and 8 stack entries
+    // per lane has room for 104 nodes; 105 and the seventh block is gone, -6 %, though the occupancy query still says 7).  C1 +3.6 %, C2 +2.0 %, C3 +4.9 %, C5 +-0;
     // trees that stream from HBM get none (C4 -2.4 % with it: stack_cap_of()).
     const int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
     const size_t stack_lds = (size_t)(stack_cap_of(ctx) < depth ? stack_cap_of(ctx) : depth) * kBlock * sizeof(uint2);
@@ -400,9 +402,9 @@ int choose_render(hpt_ctx *ctx, render_fn &fn, uint32_t &n_lds_nodes) {
     int rc = kernel_shape(ctx, (const void *)fn, stack_lds, per_cu);
     if (rc) return rc;
     if (ctx->blocks_per_cu_cap > 0 && per_cu > ctx->blocks_per_cu_cap) per_cu = ctx->blocks_per_cu_cap;
-    if (streaming_tree(ctx) && per_cu > 6) per_cu = 6;
+    if (streaming_tree(ctx) && ctx->blocks_per_cu_cap == 0 && per_cu > 6) per_cu = 6;
     long n_top = (ctx->lds_top < 0 && streaming_tree(ctx)) ? 0 : ctx->lds_top;
-    if (n_top < 0 && per_cu >= 1) n_top = ((long)((ctx->lds_per_cu / (size_t)per_cu) & ~(size_t)511) - (long)stack_lds) / (long)sizeof(WideNode);
+    if (n_top < 0 && per_cu >= 1) n_top = ((long)(ctx->lds_per_cu / (size_t)per_cu / kLdsGranule * kLdsGranule) - (long)stack_lds) / (long)sizeof(WideNode);
     if (n_top > ctx->n_wide) n_top = ctx->n_wide;
     if (n_top > kLdsTopMax) n_top = kLdsTopMax;
     if (n_top < 0 || ctx->root_ref < 0 || ctx->root_ref == HPT_REF_DONE) n_top = 0;
@@ -543,7 +545,7 @@ int launch_render(hpt_ctx *ctx, float *d_image, int spp_begin, int spp_end, int 
             long blocks = blocks_max;
             // a tree that does not fit the 256-MB Infinity Cache streams from HBM, and a seventh block per CU only adds
             // misses in flight (C4 166 -> 171 ms; 378 MB -1.1 %, 126 MB +0.9 %): six blocks per CU for those
-            if (ctx->tree_bytes > kStreamingTreeBytes && blocks > 6L * ctx->n_cu) blocks = 6L * ctx->n_cu;
+            if (streaming_tree(ctx) && ctx->blocks_per_cu_cap == 0 && blocks > 6L * ctx->n_cu) blocks = 6L * ctx->n_cu;      // (HPT_BLOCKS_PER_CU overrides)
             // a launch of fewer than four paths per lane is mostly ramp and drain: one block per CU fewer then
             // (C1's 1 M paths: 0.737 -> 0.708 ms at 6 instead of 7 blocks per CU; from ~8 paths per lane the full grid wins)
             if (blocks >= 7L * ctx->n_cu && (long)p.n_work < 4L * blocks * kBlock) blocks -= ctx->n_cu;
