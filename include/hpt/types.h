@@ -107,7 +107,7 @@ typedef struct {
     double   shade_ms;         /* iter_first_shade_kernel / iter_bounce_shade_kernel of the same call */
     double   reconstruct_ms;   /* the last hpt_reconstruct_paths or hpt_reconstruct */
     uint64_t lane_loads;       /* 16-B per-lane loads issued by the traversal and the shading of the counted rays (4 per node
-                                  visit, 5 per pair record / 3 per single record, 2 per shaded triangle hit): the unit of the
+                                  visit that is not served from the LDS copy of the tree's top, 5 per pair record / 3 per single record, 2 per shaded triangle hit): the unit of the
                                   vector-L1 gather roofline.  Counted only by contexts created with
                                   HPT_COUNT_LANE_LOADS=1 in the environment (a counting build of the kernel, 1.4 % slower);
                                   0 otherwise */

@@ -408,7 +408,7 @@ int choose_render(hpt_ctx *ctx, render_fn &fn, uint32_t &n_lds_nodes) {
     if (n_top > ctx->n_wide) n_top = ctx->n_wide;
     if (n_top > kLdsTopMax) n_top = kLdsTopMax;
     if (n_top < 0 || ctx->root_ref < 0 || ctx->root_ref == HPT_REF_DONE) n_top = 0;
-    for (; n_top > 0; n_top -= 8) {                   // the occupancy query has the last word
+    for (; n_top > 0 && ctx->lds_top < 0; n_top -= 8) {   // the occupancy query has the last word (a count fixed by HPT_LDS_TOP_NODES is taken as is: fewer blocks then)
         int with_top = 0;
         if ((rc = kernel_shape(ctx, (const void *)fn, stack_lds + (size_t)n_top * sizeof(WideNode), with_top))) return rc;
         if (with_top >= per_cu) break;

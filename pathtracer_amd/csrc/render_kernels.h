@@ -736,7 +736,8 @@ __device__ __forceinline__ void trav_tri_steps(const RenderParams &p, Trav &s, u
 template <bool COUNT, bool PAIR = false>
 __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, uint2 *stack, int stride, uint2 *spill,
                                                 int n_in, unsigned long long &loads, const float4 *lds_nodes = nullptr) {
-    if (COUNT) loads += (unsigned)(n_in * 4);
+    // (counting build) global lane-loads only: a visit served from the LDS copy of the tree's top asks nothing of the L1
+    if (COUNT) loads += 4u * (unsigned)__popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE && (unsigned)s.cur >= p.n_lds_nodes));
     int n_now = n_in;
     for (;;) {
 #ifdef HPT_PROFILE_STEPS
@@ -840,7 +841,7 @@ __device__ __forceinline__ void trav_node_steps(const RenderParams &p, Trav &s, 
         const int again = __popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE));
         if (again < p.node_repeat_min) break;
         n_now = again;
-        if (COUNT) loads += (unsigned)(again * 4);
+        if (COUNT) loads += 4u * (unsigned)__popcll(hpt_ballot((unsigned)s.cur < (unsigned)HPT_REF_IDLE && (unsigned)s.cur >= p.n_lds_nodes));
     }
 }
 

@@ -202,10 +202,16 @@ def test_config_diffuse_scale_depth_and_rr():
                                  dict(HPT_TRIS_PER_TRIP="64", HPT_NODE_REPEAT_MIN="1", HPT_BLOCKS_PER_CU="1"),
                                  dict(HPT_TRI_WEIGHT="1"), dict(HPT_TRI_WEIGHT="256", HPT_SHADE_THRESHOLD="7"),
                                  dict(HPT_PAIR_FETCH="1", HPT_LEAF_RECORDS="singles"),       # the helper-lane NODE fetch of gigabyte trees
-                                 dict(HPT_PAIR_FETCH="1", HPT_LEAF_RECORDS="singles", HPT_NODE_REPEAT_MIN="1", HPT_STACK_CAP="2")])
+                                 dict(HPT_PAIR_FETCH="1", HPT_LEAF_RECORDS="singles", HPT_NODE_REPEAT_MIN="1", HPT_STACK_CAP="2"),
+                                 # the LDS copy of the tree's top: none, the root alone, a partial level, more nodes than fit beside
+                                 # the stacks at full occupancy (fewer blocks per CU then), and with the helper-lane fetch
+                                 dict(HPT_LDS_TOP_NODES="0"), dict(HPT_LDS_TOP_NODES="1"), dict(HPT_LDS_TOP_NODES="45", HPT_STACK_CAP="10"),
+                                 dict(HPT_LDS_TOP_NODES="1024", HPT_STACK_CAP="2"),
+                                 dict(HPT_LDS_TOP_NODES="37", HPT_PAIR_FETCH="1", HPT_LEAF_RECORDS="singles")])
 def test_scheduling_knobs_do_not_change_results(env, monkeypatch):
     """The wave scheduler's knobs (which step kind runs, how long, how much of the traversal stack sits in
-    LDS before it overflows to HBM) only reorder work between lanes: every image stays bit-exact.
+    LDS before it overflows to HBM, how many nodes of the tree's top every block keeps in LDS) only reorder work
+    between lanes or change where a node is read from: every image stays bit-exact.
     HPT_STACK_CAP=1 pushes almost every stack entry through the HBM overflow path."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -723,10 +729,17 @@ def test_stats_per_stage_times_and_lane_loads(monkeypatch):
         assert torch.equal(d2.view(torch.int32), keep.view(torch.int32))
         assert (st2["launches"] > 1) == bool(budget) and st2["last_kernel_ms"] > 0 and st2["fold_ms"] > 0
         rays = st2["rays_primary"] + st2["rays_bounce"]
-        # a ray that enters the tree loads at least the root's node (4 lane-loads); C3-like scenes ~260 per ray
+        # global lane-loads: node visits below the LDS-resident top of the tree (4 each) and triangle records; C3-like scenes ~230 per ray
         assert 4 * st2["rays_primary"] <= st2["lane_loads"] <= 2000 * rays
         loads.append(st2["lane_loads"])
     assert loads[0] == loads[1]
+    # without the LDS copy of the tree's top every node visit is four global lane-loads: more of them, the same image
+    monkeypatch.setenv("HPT_LDS_TOP_NODES", "0")
+    be3 = backend_for(s, bvh)
+    d3 = dev_image(be3)
+    be3.render(0, 6, d3.data_ptr()); be3.synchronize()
+    assert torch.equal(d3.view(torch.int32), keep.view(torch.int32))
+    assert be3.stats()["lane_loads"] > 1.1 * loads[0]
 
 
 def test_full_size_properties_c4(monkeypatch):
