@@ -151,8 +151,11 @@ int hpt_read_image(hpt_ctx *ctx, const float *d_image, float *image_rgb);
  * places both in a static device array of hpt_noalloc_scratch_bytes() = 128 MiB that every GPU the library runs on
  * holds until the process ends, and cuts the render into as many launches as that takes.  It calls no hipMalloc,
  * hipFree, hipEventCreate or any other allocating routine, and records no events (hpt_get_stats reports the ray
- * counters of the call, times read 0).  Limits: the scene must be resident (hpt_upload_bvh and hpt_upload_triangles
- * done: the uploads build the device data), else HPT_ERR_INVALID; the stack overflow may take half of the array --
+ * counters of the call, times read 0).  The kernel's launch shape (function attribute, occupancy at its LDS size)
+ * is queried when the scene becomes resident -- by the uploads and hpt_set_scene -- so that no call here is the first to ask
+ * the runtime; a caller under graph capture needs no warm-up call.  Limits: the scene must be resident (hpt_upload_bvh and hpt_upload_triangles
+ * done: the uploads build the device data; after replacing only ONE of the two in a resident context, upload the other as
+ * well or call hpt_render once), else HPT_ERR_INVALID; the stack overflow may take half of the array --
  * the grid is shrunk until it does, and a tree for which not even one block per CU fits is refused with
  * HPT_ERR_INVALID (no tree that hpt_upload_bvh accepts, depth <= 64, comes near that on a 256-CU device); the rest
  * holds the samples of one launch, at least one 8x8 tile x one iteration, so any frame size and sample count
