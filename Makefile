@@ -29,7 +29,7 @@ HOST_SRC = pathtracer_amd/csrc/host/bvh.cpp pathtracer_amd/csrc/host/obj_reader.
            pathtracer_amd/csrc/host/host_capi.cpp pathtracer_amd/csrc/host/checkpoint.cpp
 HOST_OBJ = $(HOST_SRC:.cpp=.o)
 
-all: lib cli oracle scenes
+all: lib cli oracle scenes fake_rccl
 
 lib: pathtracer_amd/libhpt.so
 
@@ -63,6 +63,11 @@ scenes: scenes/libhpt_scenes.so
 scenes/libhpt_scenes.so: scenes/scenes.c
 	$(CC) -O2 -std=c11 -fPIC -ffp-contract=off -shared scenes/scenes.c -o $@ -lm
 
+# test infrastructure: a stand-in for RCCL whose ranks share one process and may share one GPU (tests/test_multi_gpu.py)
+fake_rccl: tests/native/libfake_rccl.so
+tests/native/libfake_rccl.so: tests/native/fake_rccl.hip
+	$(HIPCC) -O2 -std=c++17 --offload-arch=gfx950 -shared -fPIC tests/native/fake_rccl.hip -o $@
+
 # micro-benchmarks behind the roofline ceilings (profiles/): build/gather_exec, build/gather_rate, ...
 MICRO = $(patsubst bench/micro/%.hip,build/%,$(wildcard bench/micro/*.hip))
 micro: $(MICRO)
@@ -73,4 +78,4 @@ build/%: bench/micro/%.hip
 clean:
 	rm -f pathtracer_amd/libhpt.so oracle/libpt_oracle.so scenes/libhpt_scenes.so $(HOST_OBJ) pathtracer_amd/csrc/hpt_backend.o pathtracer_amd/csrc/hpt_comm.o
 
-.PHONY: all lib cli oracle scenes clean variant micro
+.PHONY: all lib cli oracle scenes clean variant micro fake_rccl

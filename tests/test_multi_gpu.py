@@ -295,3 +295,61 @@ def test_render_entry_point_gpus_2_progressive_and_resume(tmp_path):
     assert line["spp"] == 6 and np.array_equal(got, want)
     got, _ = run(["--spp", "6", "--gpus", "2", "--reduce-every", "2", "--shard", "samples"], "d.png")
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+_GROUP_REHEARSAL = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from conftest import bits, get_scene
+from pathtracer_amd import api
+s, bvh, o = get_scene("cornell", width=72, height=40)
+for n in (2, 3):
+    g = api.Group(72, 40, [0] * n)
+    g.load(s, bvh)
+    g.render(0, 2); g.render(2, 5)
+    want = o.render(0, 5)[0]
+    assert np.array_equal(bits(g.read_image()), bits(want)), ("tiles", n)
+    st = g.stats()
+    assert st["rays_primary"] == 72 * 40 * 3, st                        # the members' shards of the last call, summed
+    import ctypes
+    g.synchronize()
+    for m in range(n):                                                   # EVERY member holds the whole frame
+        host = np.empty((72 * 40, 3), np.float32)
+        assert api.lib().hpt_read_image(api.lib().hpt_group_ctx(g.g, m), ctypes.c_void_p(g.frame(m)), host.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(bits(host), bits(want)), ("tiles, member", m)
+    g.set_sharding(api.SHARD_SAMPLES)
+    g.render(0, 4); g.render(4, 7)
+    assert np.allclose(g.read_image(), o.render(0, 7)[0], rtol=1e-5, atol=1e-6), ("samples", n)
+    g.render(0, 1)                                                       # one sample: the members without one contribute zero
+    assert np.allclose(g.read_image(), o.render(0, 1)[0], rtol=1e-5, atol=1e-6), ("samples, 1 spp", n)
+    g.close()
+print("group rehearsal ok")
+'''
+
+
+@pytest.mark.gpu
+def test_group_of_several_members_sharing_the_gpu_over_a_stand_in_for_rccl(tmp_path):
+    """hpt_group's loops over SEVERAL members -- shards, slab offsets, one stream per member, ncclGroupStart/End around the
+    members' collectives -- executed on the one GPU: the members share it (HPT_GROUP_SHARED_DEVICE=1) and a test stand-in
+    for RCCL (tests/native/fake_rccl.hip, HPT_RCCL_LIB) copies between their buffers.  Tile shards of 2 and 3 members:
+    the oracle's frame bit for bit; sample shards: within 1e-5.  hpt_cli --devices 0,0: the one-device PNG byte for byte.
+    Says nothing about RCCL's own data movement (DESIGN.md 5)."""
+    from PIL import Image
+    fake = os.path.join(ROOT, "tests", "native", "libfake_rccl.so")
+    assert os.path.exists(fake), "make fake_rccl"
+    env = dict(os.environ, HPT_RCCL_LIB=fake, HPT_GROUP_SHARED_DEVICE="1")
+    r = subprocess.run([sys.executable, "-c", _GROUP_REHEARSAL % dict(root=ROOT)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "group rehearsal ok" in r.stdout, r.stderr[-3000:]
+    s, bvh, _ = get_scene("cornell", width=64, height=64)
+    obj = tmp_path / "cornell.obj"
+    _write_obj(obj, s["verts"])
+    light = [repr(x) for x in (0.0, -52.0, 5.0, 16.0, 12.0)]
+    base = [os.path.join(ROOT, "pathtracer_amd", "hpt_cli"), "--obj", str(obj), "--w", "64", "--h", "64", "--depth", "4", "--spp", "5", "--light"] + light
+    imgs = []
+    for extra in ([], ["--devices", "0,0", "--reduce-every", "2"]):
+        out = tmp_path / ("g%d.png" % len(imgs))
+        r = subprocess.run(base + extra + ["--out", str(out)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        imgs.append(np.asarray(Image.open(str(out)).convert("RGB")))
+    assert _line(r.stdout)["gpus"] == 2 and np.array_equal(imgs[0], imgs[1])
