@@ -49,9 +49,16 @@ def kernel_source_hash():
     """sha1 of the sources the render kernel is built from: PMC-derived figures in profiles/pmc_traffic.json carry
     the hash they were measured at and are reported only while it still matches (they go stale with the kernel)."""
     import hashlib
+    import re
     h = hashlib.sha1()
-    for f in ("pathtracer_amd/csrc/render_kernels.h", "pathtracer_amd/csrc/device_math.h", "pathtracer_amd/csrc/hpt_backend.hip", "Makefile"):
+    for f in ("pathtracer_amd/csrc/render_kernels.h", "pathtracer_amd/csrc/device_math.h", "pathtracer_amd/csrc/hpt_backend.hip"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
+    # of the Makefile only what reaches the kernel: the compiler flags and the two sizes they carry (round 3: a new test
+    # target in the Makefile must not make the PMC passes look stale)
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    for pat in (r"^HIPFLAGS\s*=.*?(?<!\\)$", r"^SAMPLE_BUDGET_MB\s*\?=.*$", r"^NOALLOC_SCRATCH_MB\s*\?=.*$"):
+        m = re.search(pat, mk, re.M | re.S)
+        h.update((m.group(0) if m else "").encode())
     return h.hexdigest()[:12]
 
 
