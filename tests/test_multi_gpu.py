@@ -303,19 +303,19 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np
 from conftest import bits, get_scene
 from pathtracer_amd import api
-s, bvh, o = get_scene("cornell", width=72, height=40)
+s, bvh, o = get_scene("cornell", width=100, height=52)          # 12.5 x 6.5 tiles: ragged right and bottom edges, padded slabs
 for n in (2, 3):
-    g = api.Group(72, 40, [0] * n)
+    g = api.Group(100, 52, [0] * n)
     g.load(s, bvh)
     g.render(0, 2); g.render(2, 5)
     want = o.render(0, 5)[0]
     assert np.array_equal(bits(g.read_image()), bits(want)), ("tiles", n)
     st = g.stats()
-    assert st["rays_primary"] == 72 * 40 * 3, st                        # the members' shards of the last call, summed
+    assert st["rays_primary"] == 100 * 52 * 3, st                        # the members' shards of the last call, summed
     import ctypes
     g.synchronize()
     for m in range(n):                                                   # EVERY member holds the whole frame
-        host = np.empty((72 * 40, 3), np.float32)
+        host = np.empty((100 * 52, 3), np.float32)
         assert api.lib().hpt_read_image(api.lib().hpt_group_ctx(g.g, m), ctypes.c_void_p(g.frame(m)), host.ctypes.data_as(ctypes.c_void_p)) == 0
         assert np.array_equal(bits(host), bits(want)), ("tiles, member", m)
     g.set_sharding(api.SHARD_SAMPLES)
