@@ -1069,8 +1069,12 @@ __global__ void __launch_bounds__(256, (SINGLES ? HPT_MIN_WAVES_PAIRS : LONG ? H
                         b = 0;
                     }
                 }
-                // The paths that start a ray in this step change lanes before they start it (regroup_starting())
-                regroup_starting(wantS && tv.cur != HPT_REF_IDLE, lane, r, b, out_idx, key, ctr, color, weight);
+                // The paths that start a ray in this step change lanes before they start it (regroup_starting()) -- in the
+                // instantiation for gigabyte trees only.  Round 2 re-grouped everywhere (C3 +3 %): same-octant rays in one quad
+                // share their node lines near the top of the tree.  Since round 3 the top of the tree is read from LDS, where
+                // sharing buys nothing, and the re-grouping only costs its ~60 instructions per SHADE step: without it C1 +3.5 %,
+                // C2 +2.6 %, C3 +0.4 %, C5 +-0; C4, which has no LDS copy, -0.7 % (profiles/r03_tuning.md).
+                if (PAIR) regroup_starting(wantS && tv.cur != HPT_REF_IDLE, lane, r, b, out_idx, key, ctr, color, weight);
                 if (wantS && tv.cur != HPT_REF_IDLE) trav_start<LONG>(p, tv, r.o, r.d);
             }
         } else if (nT * p.tri_weight > nN * 4) {     // a lane in the TRI state counts tri_weight / 4 lanes in the NODE state
