@@ -296,6 +296,9 @@ int ensure_pairs(hpt_ctx *ctx) {
     return choose_render(ctx, fn, n_top);      // attribute and occupancy queries now, not inside the first render call
 }
 
+constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
+constexpr size_t kPairFetchTreeBytes = (size_t)1 << 30;       // helper-lane node fetch: measured to pay at 1.26 GB, to cost 1-3 % at 378 MB
+
 int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, int spp_end, int raw) {
     if (!ctx->have_camera) return fail(ctx, HPT_ERR_INVALID, "hpt_set_camera has not been called");
     if (ctx->root_ref != HPT_REF_DONE && ctx->max_leaf_end > ctx->n_tris)
@@ -329,8 +332,11 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     p.raw_sample = raw;
     // the longer the primitive list, the dearer a SHADE step (129 primitives: ~6 000 instructions), the more lanes
     // it should wait for: C5 24 / 32 / 40 / 48 -> 2 115 / 2 235 / 2 259 / 2 204 Mrays/s; C3 (1 primitive) is best at 24
+    // ... and a tree that streams from HBM waits for misses, not for lanes: its finished rays can wait for more company
+    // (C4 20 / 24 / 28 / 32 / 36 / 40 / 48: 163.6 / 162.6 / 161.7 / 161.4 / 161.3 / 161.8 / 166.3 ms)
     p.shade_threshold = ctx->shade_threshold_fixed ? ctx->shade_threshold
-                                                   : ctx->shade_threshold + (ctx->n_prims / 8 < 16 ? ctx->n_prims / 8 : 16);
+                                                   : ctx->shade_threshold + (ctx->n_prims / 8 < 16 ? ctx->n_prims / 8 : 16) +
+                                                     (ctx->tree_bytes > kStreamingTreeBytes ? 8 : 0);
     p.tris_per_trip = ctx->tris_per_trip;
     p.node_repeat_min = ctx->node_repeat_min;
     p.tri_weight = ctx->tri_weight;
@@ -339,15 +345,13 @@ int fill_params(hpt_ctx *ctx, RenderParams &p, float *d_image, int spp_begin, in
     return HPT_OK;
 }
 
-constexpr size_t kStreamingTreeBytes = (size_t)256 << 20;     // the Infinity Cache
-constexpr size_t kPairFetchTreeBytes = (size_t)1 << 30;       // helper-lane node fetch: measured to pay at 1.26 GB, to cost 1-3 % at 378 MB
-
 // LDS stack entries per lane.  Cache-resident trees: 8, which leaves room for 104 nodes of the tree's top in LDS at 7 blocks
 // per CU (8 + 104 beat 10 + 40 and 9 + 72 at C3; without the node copy 8, 9 and 10 tie: profiles/r03/lds_top/).  Trees that
-// stream from HBM keep 10 and no node copy: at C4 every entry that overflows to HBM is one more miss in a kernel that waits
-// for misses (cap 8: -3.3 %; with the node copy on top: -6 %).
+// stream from HBM get no node copy and all the LDS of their six blocks per CU as stack: 13 entries (13 x 2 KB = 26 624 B, 21 granules
+// of 1 280 B, six times in 160 KB).  At C4 every entry that overflows to HBM is one more miss in a kernel that waits for misses:
+// 8 / 10 / 11 / 12 / 13 entries 169.6 / 164.5 / 163.3 / 162.9 / 162.7 ms; the node copy on top of 10: -2.4 %.
 bool streaming_tree(const hpt_ctx *ctx) { return ctx->tree_bytes > kStreamingTreeBytes; }
-int stack_cap_of(const hpt_ctx *ctx) { return ctx->stack_cap > 0 ? ctx->stack_cap : streaming_tree(ctx) ? 10 : 8; }
+int stack_cap_of(const hpt_ctx *ctx) { return ctx->stack_cap > 0 ? ctx->stack_cap : streaming_tree(ctx) ? 13 : 8; }
 
 size_t stack_lds_bytes(const hpt_ctx *ctx, int block) {
     int depth = ctx->tree_depth > 0 ? ctx->tree_depth : 1;
