@@ -56,8 +56,8 @@ def kernel_source_hash():
     # of the Makefile only what reaches the kernel: the compiler flags and the two sizes they carry (round 3: a new test
     # target in the Makefile must not make the PMC passes look stale)
     mk = open(os.path.join(ROOT, "Makefile")).read()
-    for pat in (r"^HIPFLAGS\s*=.*?(?<!\\)$", r"^SAMPLE_BUDGET_MB\s*\?=.*$", r"^NOALLOC_SCRATCH_MB\s*\?=.*$"):
-        m = re.search(pat, mk, re.M | re.S)
+    for pat in (r"^HIPFLAGS\s*=(?:[^\n]*\\\n)*[^\n]*$", r"^SAMPLE_BUDGET_MB\s*\?=[^\n]*$", r"^NOALLOC_SCRATCH_MB\s*\?=[^\n]*$"):
+        m = re.search(pat, mk, re.M)
         h.update((m.group(0) if m else "").encode())
     return h.hexdigest()[:12]
 

@@ -371,3 +371,33 @@ def test_integration_forwarding_body_compiles(tmp_path):
                         "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "pathtracer_amd"), "-Wl,-rpath,/opt/rocm/lib"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_kernel_source_hash_follows_the_kernel_not_the_whole_makefile(tmp_path, monkeypatch):
+    """bench.kernel_source_hash() stamps the PMC figures of profiles/pmc_traffic.json: it must change with the kernel
+    sources and the compiler flags, and with nothing else (round 3: a new test target in the Makefile made every PMC
+    pass look stale)."""
+    import shutil
+    import bench
+    for f in ("pathtracer_amd/csrc/render_kernels.h", "pathtracer_amd/csrc/device_math.h", "pathtracer_amd/csrc/hpt_backend.hip", "Makefile"):
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        shutil.copy(os.path.join(ROOT, f), tmp_path / f)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    h0 = bench.kernel_source_hash()
+    assert h0 == __import__("importlib").import_module("bench").kernel_source_hash()
+    mk = (tmp_path / "Makefile").read_text()
+    (tmp_path / "Makefile").write_text(mk + "\nsome_new_target:\n\techo nothing about the kernel\n")
+    assert bench.kernel_source_hash() == h0
+    (tmp_path / "Makefile").write_text(mk.replace("-fno-slp-vectorize", "-fno-slp-vectorize -DSOMETHING=1"))
+    assert bench.kernel_source_hash() != h0
+    (tmp_path / "Makefile").write_text(mk.replace("SAMPLE_BUDGET_MB ?= 2048", "SAMPLE_BUDGET_MB ?= 4096"))
+    assert bench.kernel_source_hash() != h0
+    (tmp_path / "Makefile").write_text(mk)
+    with open(tmp_path / "pathtracer_amd/csrc/device_math.h", "a") as f:
+        f.write("// x\n")
+    assert bench.kernel_source_hash() != h0
+    # the stored PMC figures belong to the kernel in the tree
+    monkeypatch.setattr(bench, "ROOT", ROOT)
+    import json
+    stored = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert {v["kernel_source_hash"] for v in stored.values()} == {bench.kernel_source_hash()}
